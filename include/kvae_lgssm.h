@@ -1,0 +1,146 @@
+/*
+ * kvae_lgssm.h — C ABI of the MI355X-native LGSSM hot path of the Kalman-VAE
+ * (libkvae_lgssm.so, built from kalman-vae_amd/csrc/kvae_lgssm.hip for gfx950).
+ *
+ * The reference (rodrigo-paganini/kalman-vae) has no FFI layer: this path lives behind the
+ * Python class kvae.kalman.kalman_filter.KalmanFilter.  Each entry point below replaces the
+ * aten-op sequence of one reference method; the file:line it replaces is cited on the function.
+ * All pointers are DEVICE pointers to fp32, row-major; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Calls are asynchronous: nothing here synchronises, allocates
+ * or frees, so every call may be captured into a hipGraph.  Return value: kvae_status.
+ *
+ * Shapes: B sequences, T steps, n = dim z, m = dim u, p = dim a (all of n,m,p <= KVAE_MAX_DIM).
+ */
+#ifndef KVAE_LGSSM_H
+#define KVAE_LGSSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVAE_MAX_DIM 16
+#define KVAE_ABI_VERSION 1
+
+typedef enum {
+  KVAE_OK = 0,
+  KVAE_ERR_DIMS = 1,   /* n, m or p outside [1, KVAE_MAX_DIM], or B/T < 1              */
+  KVAE_ERR_NULL = 2,   /* a required pointer is NULL                                    */
+  KVAE_ERR_LAUNCH = 3, /* hipLaunchKernel / hipMemsetAsync failed (see kvae_last_error) */
+  KVAE_ERR_ARG = 4     /* inconsistent arguments (e.g. K < 1)                           */
+} kvae_status;
+
+/* One per-step operand: element (b, t) starts at ptr + b*sb + t*st (strides in floats).
+ * sb = st = 0 broadcasts a single matrix (K == 1 dynamics, constant Q). */
+typedef struct {
+  const float *ptr;
+  int64_t sb, st;
+} kvae_stack;
+
+/* The LGSSM problem: what KalmanFilter.filter/smooth/elbo read (kalman_filter.py:8-28,107-150). */
+typedef struct {
+  int32_t B, T, n, m, p;
+  kvae_stack A;            /* [n,n]  transition        A_t  (kalman_filter.py:153-160)      */
+  kvae_stack Bm;           /* [n,m]  control           B_t                                  */
+  kvae_stack C;            /* [p,n]  emission          C_t                                  */
+  kvae_stack Q;            /* [n,n]  process noise     Q_t  (self.Q buffer or dyn.Q_seq)    */
+  const float *R;          /* [p,p]  observation noise (kalman_filter.py:23)                */
+  const float *mu0;        /* [n]    belief on z_{-1}; per sequence when mu0_sb != 0        */
+  int64_t mu0_sb;
+  const float *Sigma0;     /* [n,n]                                                         */
+  int64_t Sigma0_sb;
+  const float *Y;          /* [B,T,p] contiguous observations a_t                           */
+  const float *U;          /* [B,T,m] contiguous controls                                   */
+  const float *mask;       /* [B,T] 1 = observed, 0 = missing; NULL = all observed          */
+} kvae_lgssm_problem;
+
+/* Filtered / predicted / smoothed beliefs, each [B,T,...] contiguous (kalman_filter.py:193-201,274-279). */
+typedef struct {
+  float *mus_filt;      /* [B,T,n]   */
+  float *Sigmas_filt;   /* [B,T,n,n] */
+  float *mus_pred;      /* [B,T,n]   */
+  float *Sigmas_pred;   /* [B,T,n,n] */
+  float *mus_smooth;    /* [B,T,n]   (NULL for filter-only calls) */
+  float *Sigmas_smooth; /* [B,T,n,n] */
+} kvae_lgssm_states;
+
+/* Writable counterpart of kvae_stack: element (b,t) of a gradient stack starts at
+ * ptr + b*sb + t*st.  Lets gA/gB/gC/gQ land directly in the slots of one packed [B,T,E] record. */
+typedef struct {
+  float *ptr;
+  int64_t sb, st;
+} kvae_gstack;
+
+/* Gradients w.r.t. the problem's per-step inputs.  gA, gB, gC, gY are required by the backward
+ * entry points; gQ.ptr, gU, g_mu0, g_Sigma0 may be NULL (not wanted).
+ * gY [B,T,p], gU [B,T,m] contiguous; g_mu0 [B,n], g_Sigma0 [B,n,n] per sequence. */
+typedef struct {
+  kvae_gstack gA, gB, gC, gQ; /* per step [n,n] [n,m] [p,n] [n,n] */
+  float *gY, *gU;
+  float *g_mu0, *g_Sigma0;
+} kvae_lgssm_input_grads;
+
+/* ---- forward ------------------------------------------------------------------------------ */
+
+/* Kalman filter over T steps from (mu0, Sigma0): replaces KalmanFilter.filter's time loop and
+ * filter_step (kalman_filter.py:31-104, 151-201). Writes the four filt/pred stacks. */
+int kvae_lgssm_filter_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream);
+
+/* RTS smoother over already-filtered beliefs: replaces smooth_step and the reverse loop of
+ * KalmanFilter.smooth (kalman_filter.py:204-237, 249-272). Reads filt/pred, writes smooth. */
+int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *io, void *stream);
+
+/* Filter + RTS in ONE launch (one wavefront per sequence, whole T loop in-kernel):
+ * replaces KalmanFilter.smooth (kalman_filter.py:240-279). Writes all six stacks. */
+int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream);
+
+/* ---- backward ----------------------------------------------------------------------------- */
+
+/* Reverse-mode of kvae_lgssm_smooth_fwd (with_rts = 1) or kvae_lgssm_filter_fwd (with_rts = 0):
+ * replaces what autograd records for kalman_filter.py:151-185, 257-272.  `saved` holds the forward
+ * results; `up` holds upstream gradients of the six stacks (any pointer may be NULL = zero).
+ * Scratch: ws [B,T,2*(n+n*n)] floats (adjoints handed from the smoother sweep to the filter sweep). */
+int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved,
+                          const kvae_lgssm_states *up, const kvae_lgssm_input_grads *out,
+                          float *ws, int with_rts, void *stream);
+
+/* ---- ELBO --------------------------------------------------------------------------------- */
+
+/* The LGSSM terms of KalmanFilter.elbo (kalman_filter.py:347-389) for z = mu_s + chol(Sigma_s) eps:
+ *   terms[(b*T + t)*4 + {0,1,2,3}] = {transition, emission, init, entropy} of step (b,t)
+ * (the caller adds log p(s) - log q(s) and divides by mask.sum().clamp(1), :392-400).
+ * _safe_cholesky (kalman_filter.py:282-302) is reproduced as a whole-batch jitter level resolved
+ * on the device: chol_levels[0] (Sigma_s) and chol_levels[1] (Q_t) receive the first level
+ * 0..4 (jitter 1e-6 * 10^level) at which every factorisation succeeds, or 5 = diagonal fallback.
+ * If `g` / g_mus / g_Sigmas are non-NULL the gradients of SUM(terms) w.r.t. mus_smooth,
+ * Sigmas_smooth and the problem inputs are written as well (unit upstream; the caller scales).
+ * eps: [B,T,n] standard normal draws. chol_levels: 2 ints of device scratch (zeroed by the call). */
+int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth,
+                    const float *eps, float *terms, int32_t *chol_levels, float *g_mus, float *g_Sigmas,
+                    const kvae_lgssm_input_grads *g, void *stream);
+
+/* ---- mixture-of-K dynamics ---------------------------------------------------------------- */
+
+/* out[r, :] = sum_k alpha[r, k] * base[k, :] for r < rows (= B*T), E = row length, K <= 16.
+ * Replaces the einsums of dyn_param.py:58-60 and switch_dyn_param.py:82-84; the host side packs
+ * A|B|C (lstm) or A|B|Q (switching) into ONE [K,E] base so that one launch mixes a whole step record. */
+int kvae_mix_fwd(const float *alpha, const float *base, float *out, int64_t rows, int32_t K, int32_t E,
+                 void *stream);
+
+/* g_alpha[r,k] (+)= <g_out[r,:], base[k,:]>;  g_base[k,:] = sum_r alpha[r,k] g_out[r,:].
+ * accumulate_alpha != 0 adds into g_alpha (several mixed operands share one alpha).
+ * partials: scratch of kvae_mix_bwd_partials(rows) * K * E floats (deterministic two-stage sum). */
+int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, float *g_alpha, float *g_base,
+                 float *partials, int64_t rows, int32_t K, int32_t E, int32_t accumulate_alpha, void *stream);
+int64_t kvae_mix_bwd_partials(int64_t rows);
+
+/* ---- misc --------------------------------------------------------------------------------- */
+int kvae_abi_version(void);
+const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */
+const char *kvae_build_info(void); /* "gfx950 ..." */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVAE_LGSSM_H */

@@ -1,0 +1,217 @@
+// kvae_lgssm.hip — gfx950 kernels and the C ABI (include/kvae_lgssm.h) of the LGSSM hot path.
+//
+// Launch geometry: every workgroup is ONE 64-lane wavefront.
+//   smooth / filter / rts / backward : grid = B   (one wavefront per sequence, T loop in-kernel)
+//   elbo probe / elbo                : grid = B*T (one wavefront per (sequence, step))
+//   mix                              : 256-thread element-wise / slab-reduction kernels
+// Dimensions (n,m,p) = (4,4,2) and (16,16,2) get fully unrolled compile-time specialisations;
+// anything else (<= 16) runs the run-time-dimension instantiation of the same bodies.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include "lgssm_bwd.h"
+#include "lgssm_elbo.h"
+#include "lgssm_fwd.h"
+#include "mix.h"
+
+using namespace kvae;
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <class D>
+__global__ __launch_bounds__(64) void k_smooth_fwd(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter,
+                                                   int do_rts) {
+  __shared__ FwdLds<D> L;
+  const D d(P.n, P.m, P.p);
+  const int b = blockIdx.x;
+  if (do_filter) {
+    filter_sweep(d, P, S, b, L);
+    KV_SYNC();
+  }
+  if (do_rts) rts_sweep(d, P, S, b, L);
+}
+
+template <class D>
+__global__ __launch_bounds__(64) void k_smooth_bwd(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
+                                                   kvae_lgssm_input_grads G, float *ws, int with_rts) {
+  __shared__ BwdLds<D> L;
+  const D d(P.n, P.m, P.p);
+  const int b = blockIdx.x;
+  if (with_rts)
+    rts_bwd_sweep(d, P, S, U, G, ws, b, L);
+  else
+    filter_bwd_seed(d, P, U, G, ws, b);
+  KV_SYNC();
+  filter_bwd_sweep(d, P, S, G, ws, b, L);
+}
+
+template <class D>
+__global__ __launch_bounds__(64) void k_elbo_probe(kvae_lgssm_problem P, const float *Sig_s, int32_t *levels) {
+  __shared__ ElboLds<D> L;
+  const D d(P.n, P.m, P.p);
+  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
+  elbo_probe_body(d, P, Sig_s, levels, b, t, L);
+}
+
+template <class D>
+__global__ __launch_bounds__(64) void k_elbo(kvae_lgssm_problem P, const float *mus, const float *Sigs,
+                                             const float *eps, float *terms, const int32_t *levels, float *g_mus,
+                                             float *g_Sigs, kvae_lgssm_input_grads G, int have_g) {
+  __shared__ ElboLds<D> L;
+  const D d(P.n, P.m, P.p);
+  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
+  elbo_body(d, P, mus, Sigs, eps, terms, levels, g_mus, g_Sigs, have_g ? &G : nullptr, b, t, L);
+}
+
+__global__ __launch_bounds__(256) void k_mix_fwd(const float *alpha, const float *base, float *out, int64_t total,
+                                                 int K, int E) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) mix_fwd_elem(alpha, base, out, idx, K, E);
+}
+
+__global__ __launch_bounds__(256) void k_mix_bwd_alpha(const float *base, const float *g_out, float *g_alpha,
+                                                       int64_t total, int K, int E, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) mix_bwd_alpha_elem(base, g_out, g_alpha, idx, K, E, accumulate);
+}
+
+__global__ void k_mix_bwd_partial(const float *alpha, const float *g_out, float *partials, int64_t rows, int K, int E) {
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e < E) mix_bwd_partial_elem(alpha, g_out, partials, blockIdx.x, e, rows, K, E);
+}
+
+__global__ __launch_bounds__(256) void k_mix_bwd_final(const float *partials, float *g_base, int64_t nblk, int KE) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < KE) mix_bwd_final_elem(partials, g_base, idx, nblk, KE);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: validation, dispatch on (n,m,p), launch
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+static int launch_status(const char *what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return KVAE_OK;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return KVAE_ERR_LAUNCH;
+}
+
+static int check_problem(const kvae_lgssm_problem *p) {
+  if (!p) return KVAE_ERR_NULL;
+  if (p->B < 1 || p->T < 1 || p->n < 1 || p->m < 1 || p->p < 1 || p->n > KVAE_MAX_DIM || p->m > KVAE_MAX_DIM ||
+      p->p > KVAE_MAX_DIM)
+    return KVAE_ERR_DIMS;
+  if (!p->A.ptr || !p->Bm.ptr || !p->C.ptr || !p->Q.ptr || !p->R || !p->mu0 || !p->Sigma0 || !p->Y || !p->U)
+    return KVAE_ERR_NULL;
+  return KVAE_OK;
+}
+
+#define KVAE_DISPATCH(P, ...)                                    \
+  do {                                                           \
+    if ((P).n == 4 && (P).m == 4 && (P).p == 2) {               \
+      using D = SDims<4, 4, 2>;                                  \
+      __VA_ARGS__;                                                   \
+    } else if ((P).n == 16 && (P).m == 16 && (P).p == 2) {      \
+      using D = SDims<16, 16, 2>;                                \
+      __VA_ARGS__;                                                   \
+    } else {                                                     \
+      using D = RDims;                                           \
+      __VA_ARGS__;                                                   \
+    }                                                            \
+  } while (0)
+
+static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int do_filter, int do_rts,
+                      void *stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!st || !st->mus_filt || !st->Sigmas_filt || !st->mus_pred || !st->Sigmas_pred) return KVAE_ERR_NULL;
+  if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  KVAE_DISPATCH(*prob, k_smooth_fwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts));
+  return launch_status("k_smooth_fwd");
+}
+
+extern "C" {
+
+int kvae_lgssm_filter_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream) {
+  return launch_fwd(prob, out, 1, 0, stream);
+}
+int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *io, void *stream) {
+  return launch_fwd(prob, io, 0, 1, stream);
+}
+int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream) {
+  return launch_fwd(prob, out, 1, 1, stream);
+}
+
+int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                          const kvae_lgssm_input_grads *out, float *ws, int with_rts, void *stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!saved || !up || !out || !ws) return KVAE_ERR_NULL;
+  if (!saved->mus_filt || !saved->Sigmas_filt || !saved->mus_pred || !saved->Sigmas_pred) return KVAE_ERR_NULL;
+  if (with_rts && (!saved->mus_smooth || !saved->Sigmas_smooth)) return KVAE_ERR_NULL;
+  if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  KVAE_DISPATCH(*prob, k_smooth_bwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws,
+                                           with_rts));
+  return launch_status("k_smooth_bwd");
+}
+
+int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth, const float *eps,
+                    float *terms, int32_t *chol_levels, float *g_mus, float *g_Sigmas, const kvae_lgssm_input_grads *g,
+                    void *stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!mus_smooth || !Sigmas_smooth || !eps || !terms || !chol_levels) return KVAE_ERR_NULL;
+  const bool want_g = (g_mus != nullptr);
+  if (want_g && (!g_Sigmas || !g || !g->gA.ptr || !g->gB.ptr || !g->gC.ptr || !g->gY)) return KVAE_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(chol_levels, 0, 2 * sizeof(int32_t), s) != hipSuccess) return launch_status("memset chol_levels");
+  const unsigned grid = (unsigned)((int64_t)prob->B * prob->T);
+  KVAE_DISPATCH(*prob, k_elbo_probe<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, Sigmas_smooth, chol_levels));
+  rc = launch_status("k_elbo_probe");
+  if (rc) return rc;
+  kvae_lgssm_input_grads gz;
+  memset(&gz, 0, sizeof(gz));
+  KVAE_DISPATCH(*prob, k_elbo<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps,
+                                           terms, (const int32_t *)chol_levels, g_mus, g_Sigmas, want_g ? *g : gz,
+                                           want_g ? 1 : 0));
+  return launch_status("k_elbo");
+}
+
+int kvae_mix_fwd(const float *alpha, const float *base, float *out, int64_t rows, int32_t K, int32_t E, void *stream) {
+  if (!alpha || !base || !out) return KVAE_ERR_NULL;
+  if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
+  const int64_t total = rows * E;
+  hipLaunchKernelGGL(k_mix_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, alpha, base, out,
+                     total, K, E);
+  return launch_status("k_mix_fwd");
+}
+
+int64_t kvae_mix_bwd_partials(int64_t rows) { return (rows + KVAE_MIX_ROWS_PER_BLOCK - 1) / KVAE_MIX_ROWS_PER_BLOCK; }
+
+int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, float *g_alpha, float *g_base, float *partials,
+                 int64_t rows, int32_t K, int32_t E, int32_t accumulate_alpha, void *stream) {
+  if (!alpha || !base || !g_out || !g_alpha || !g_base || !partials) return KVAE_ERR_NULL;
+  if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t ta = rows * K;
+  hipLaunchKernelGGL(k_mix_bwd_alpha, dim3((unsigned)((ta + 255) / 256)), dim3(256), 0, s, base, g_out, g_alpha, ta, K, E,
+                     accumulate_alpha);
+  const int64_t nblk = kvae_mix_bwd_partials(rows);
+  const int tpb = E >= 256 ? 256 : ((E + 63) / 64) * 64;
+  hipLaunchKernelGGL(k_mix_bwd_partial, dim3((unsigned)nblk, (unsigned)((E + tpb - 1) / tpb)), dim3(tpb), 0, s, alpha, g_out,
+                     partials, rows, K, E);
+  hipLaunchKernelGGL(k_mix_bwd_final, dim3((unsigned)((K * E + 255) / 256)), dim3(256), 0, s, partials, g_base, nblk, K * E);
+  return launch_status("k_mix_bwd");
+}
+
+int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
+const char *kvae_last_error(void) { return g_err; }
+const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "1"; }
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""ctypes binding of the C ABI in include/kvae_lgssm.h (libkvae_lgssm.so, gfx950).
+
+There is NO CPU implementation behind this module: if the HIP library has not been built
+(`python __graft_entry__.py build`) or no HIP device is visible, the ops raise.  The only way to
+run the op layer on host tensors is for a TEST to inject the host simulator of the kernel bodies
+(tests/hostsim) through `_set_test_backend`; product code never does that.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
+
+KVAE_MAX_DIM = 16
+KVAE_MAX_K = 16
+ABI_VERSION = 1
+
+_STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
+           4: "KVAE_ERR_ARG"}
+
+
+class Stack(C.Structure):  # kvae_stack / kvae_gstack (same layout)
+    _fields_ = [("ptr", C.c_void_p), ("sb", C.c_int64), ("st", C.c_int64)]
+
+
+class Problem(C.Structure):  # kvae_lgssm_problem
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("p", C.c_int32),
+                ("A", Stack), ("Bm", Stack), ("C", Stack), ("Q", Stack),
+                ("R", C.c_void_p), ("mu0", C.c_void_p), ("mu0_sb", C.c_int64),
+                ("Sigma0", C.c_void_p), ("Sigma0_sb", C.c_int64),
+                ("Y", C.c_void_p), ("U", C.c_void_p), ("mask", C.c_void_p)]
+
+
+class States(C.Structure):  # kvae_lgssm_states
+    _fields_ = [(k, C.c_void_p) for k in ("mus_filt", "Sigmas_filt", "mus_pred", "Sigmas_pred",
+                                          "mus_smooth", "Sigmas_smooth")]
+
+
+class InputGrads(C.Structure):  # kvae_lgssm_input_grads
+    _fields_ = [("gA", Stack), ("gB", Stack), ("gC", Stack), ("gQ", Stack),
+                ("gY", C.c_void_p), ("gU", C.c_void_p), ("g_mu0", C.c_void_p), ("g_Sigma0", C.c_void_p)]
+
+
+SYMBOLS = ("kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
+           "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_abi_version",
+           "kvae_last_error", "kvae_build_info")
+
+
+class LgssmLib:
+    """One loaded implementation of the C ABI."""
+
+    def __init__(self, path):
+        self.path = str(path)
+        self.dll = C.CDLL(self.path)
+        missing = [s for s in SYMBOLS if not hasattr(self.dll, s)]
+        if missing:
+            raise OSError(f"{self.path} does not export {missing}")
+        d = self.dll
+        P, S, G, vp = C.POINTER(Problem), C.POINTER(States), C.POINTER(InputGrads), C.c_void_p
+        for name in ("kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd"):
+            getattr(d, name).argtypes = [P, S, vp]
+            getattr(d, name).restype = C.c_int
+        d.kvae_lgssm_smooth_bwd.argtypes = [P, S, S, G, vp, C.c_int, vp]
+        d.kvae_lgssm_smooth_bwd.restype = C.c_int
+        d.kvae_lgssm_elbo.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, G, vp]
+        d.kvae_lgssm_elbo.restype = C.c_int
+        d.kvae_mix_fwd.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_mix_fwd.restype = C.c_int
+        d.kvae_mix_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]
+        d.kvae_mix_bwd.restype = C.c_int
+        d.kvae_mix_bwd_partials.argtypes = [C.c_int64]
+        d.kvae_mix_bwd_partials.restype = C.c_int64
+        d.kvae_abi_version.restype = C.c_int
+        d.kvae_last_error.restype = C.c_char_p
+        d.kvae_build_info.restype = C.c_char_p
+        if d.kvae_abi_version() != ABI_VERSION:
+            raise OSError(f"{self.path}: ABI {d.kvae_abi_version()} != expected {ABI_VERSION}")
+
+    def check(self, rc, what):
+        if rc != 0:
+            detail = self.dll.kvae_last_error().decode() if rc == 3 else ""
+            raise RuntimeError(f"{what} failed: {_STATUS.get(rc, rc)} {detail}")
+
+    @property
+    def build_info(self):
+        return self.dll.kvae_build_info().decode()
+
+
+_hip_lib = None
+_test_backend = None
+
+
+def hip_lib():
+    """The gfx950 library; raises (never falls back) if it is not built."""
+    global _hip_lib
+    if _hip_lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"HIP library {LIB_PATH} is missing. Build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the LGSSM path.")
+        _hip_lib = LgssmLib(LIB_PATH)
+    return _hip_lib
+
+
+def _set_test_backend(lib):
+    """TEST-ONLY: route ops on host tensors to the host simulator of the kernel bodies."""
+    global _test_backend
+    _test_backend = lib
+
+
+def lib_for(t: torch.Tensor):
+    if t.is_cuda:
+        return hip_lib()
+    if _test_backend is not None:
+        return _test_backend
+    raise RuntimeError(
+        "kvae LGSSM ops run only on a HIP device (MI355X): got a CPU tensor and there is no CPU fallback. "
+        "Move the model and inputs to 'cuda'.")
+
+
+def stream_for(t: torch.Tensor):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

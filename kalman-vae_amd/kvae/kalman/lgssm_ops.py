@@ -1,0 +1,275 @@
+"""torch.autograd bridge to the HIP LGSSM kernels (C ABI: include/kvae_lgssm.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd graph.
+Every numerical step of filter / RTS smoother / ELBO / mixing — forward and backward — runs in
+libkvae_lgssm.so.  Nothing in this file computes on the host or falls back to aten ops.
+
+Per-step operands (A_t, B_t, C_t, Q_t) reach the kernels as strided "stacks": either slots of ONE
+packed record tensor [B,T,E] produced by `mix_dynamics` (mixture-of-K case: a single launch writes
+a whole step record, a single tensor carries its gradient) or a plain tensor that is broadcast
+([r,c]) or per-step ([B,T,r,c]).
+"""
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from .. import _native as N
+
+
+class Slots(NamedTuple):
+    """Float offsets of A|B|C|Q inside one packed step record (None = operand is not packed)."""
+    A: Optional[int] = None
+    B: Optional[int] = None
+    C: Optional[int] = None
+    Q: Optional[int] = None
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stack(t, Bsz, T, r, c, packed=None, off=None):
+    """(tensor_to_keep_alive, N.Stack) for one per-step operand."""
+    if off is not None:
+        E = packed.shape[-1]
+        return packed, N.Stack(packed.data_ptr() + 4 * off, T * E, E)
+    if t.dim() == 2:
+        t = _f32c(t)
+        return t, N.Stack(t.data_ptr(), 0, 0)
+    if t.shape != (Bsz, T, r, c):
+        t = t.expand(Bsz, T, r, c)
+    if t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride(-2) != c:
+        t = t.float().contiguous()
+    return t, N.Stack(t.data_ptr(), t.stride(0), t.stride(1))
+
+
+class _Call:
+    """Builds the kvae_lgssm_problem for one call and keeps every tensor alive until it returns."""
+
+    def __init__(self, Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots):
+        self.Y, self.U = _f32c(Y), _f32c(U)
+        Bsz, T, p = self.Y.shape
+        m = self.U.shape[-1]
+        n = Sigma0.shape[-1]
+        self.dims = (Bsz, T, n, m, p)
+        self.mask = _f32c(mask)
+        self.packed = _f32c(packed)
+        self.R, self.mu0, self.Sigma0 = _f32c(R), _f32c(mu0), _f32c(Sigma0)
+        self.keep = []
+        prob = N.Problem()
+        prob.B, prob.T, prob.n, prob.m, prob.p = Bsz, T, n, m, p
+        for name, t, r, c, off in (("A", A, n, n, slots.A), ("Bm", Bm, n, m, slots.B),
+                                   ("C", Cm, p, n, slots.C), ("Q", Q, n, n, slots.Q)):
+            keep, st = _stack(t, Bsz, T, r, c, self.packed, off)
+            self.keep.append(keep)
+            setattr(prob, name, st)
+        prob.R = self.R.data_ptr()
+        prob.mu0 = self.mu0.data_ptr()
+        prob.mu0_sb = n if self.mu0.dim() == 2 else 0
+        prob.Sigma0 = self.Sigma0.data_ptr()
+        prob.Sigma0_sb = n * n if self.Sigma0.dim() == 3 else 0
+        prob.Y, prob.U = self.Y.data_ptr(), self.U.data_ptr()
+        prob.mask = self.mask.data_ptr() if self.mask is not None else None
+        self.prob = prob
+        self.lib = N.lib_for(self.Y)
+        self.stream = N.stream_for(self.Y)
+
+
+def _states(mf, Sf, mp, Sp, ms=None, Ss=None):
+    st = N.States()
+    for k, t in (("mus_filt", mf), ("Sigmas_filt", Sf), ("mus_pred", mp), ("Sigmas_pred", Sp),
+                 ("mus_smooth", ms), ("Sigmas_smooth", Ss)):
+        setattr(st, k, t.data_ptr() if t is not None else None)
+    return st
+
+
+class _GradSink:
+    """Gradient buffers for the per-step operands + the autograd return values built from them."""
+
+    def __init__(self, call, packed, A, Bm, Cm, Q, slots, need_q):
+        Bsz, T, n, m, p = call.dims
+        dev = call.Y.device
+        self.g = N.InputGrads()
+        self.out = {}
+        self.gpacked = torch.empty_like(call.packed) if packed is not None else None
+        for name, t, r, c, off in (("gA", A, n, n, slots.A), ("gB", Bm, n, m, slots.B),
+                                   ("gC", Cm, p, n, slots.C), ("gQ", Q, n, n, slots.Q)):
+            if off is not None:
+                E = self.gpacked.shape[-1]
+                setattr(self.g, name, N.Stack(self.gpacked.data_ptr() + 4 * off, T * E, E))
+            elif name == "gQ" and not need_q:
+                setattr(self.g, name, N.Stack(None, 0, 0))
+            else:
+                buf = torch.empty(Bsz, T, r, c, device=dev, dtype=torch.float32)
+                self.out[name] = (buf, t)
+                setattr(self.g, name, N.Stack(buf.data_ptr(), T * r * c, r * c))
+        self.gY = torch.empty_like(call.Y)
+        self.gU = torch.empty_like(call.U)
+        self.g.gY, self.g.gU = self.gY.data_ptr(), self.gU.data_ptr()
+
+    def operand_grad(self, name, scale=None):
+        """Gradient for a non-packed operand, reduced to the shape the caller passed in."""
+        if name not in self.out:
+            return None
+        buf, t = self.out[name]
+        if scale is not None:
+            buf = buf * scale
+        if t.dim() == 2:
+            return buf.sum((0, 1))
+        return buf.sum_to_size(t.shape) if tuple(t.shape) != tuple(buf.shape) else buf
+
+
+# ------------------------------------------------------------------------------------------------
+# filter (+ RTS smoother)
+# ------------------------------------------------------------------------------------------------
+class LgssmSmooth(torch.autograd.Function):
+    """KalmanFilter.filter / .smooth (reference kalman_filter.py:107-201, 240-279) in one launch."""
+
+    @staticmethod
+    def forward(ctx, Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots, with_rts):
+        call = _Call(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots)
+        Bsz, T, n, m, p = call.dims
+        dev = call.Y.device
+        mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        mf, Sf, mp, Sp = mk(Bsz, T, n), mk(Bsz, T, n, n), mk(Bsz, T, n), mk(Bsz, T, n, n)
+        ms, Ss = (mk(Bsz, T, n), mk(Bsz, T, n, n)) if with_rts else (None, None)
+        st = _states(mf, Sf, mp, Sp, ms, Ss)
+        fn = call.lib.dll.kvae_lgssm_smooth_fwd if with_rts else call.lib.dll.kvae_lgssm_filter_fwd
+        call.lib.check(fn(C.byref(call.prob), C.byref(st), call.stream), "kvae_lgssm_smooth_fwd")
+        ctx.slots, ctx.with_rts = slots, with_rts
+        ctx.save_for_backward(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss)
+        if with_rts:
+            return ms, Ss, mf, Sf, mp, Sp
+        return mf, Sf, mp, Sp
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss = ctx.saved_tensors
+        slots, with_rts = ctx.slots, ctx.with_rts
+        call = _Call(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots)
+        Bsz, T, n, m, p = call.dims
+        if with_rts:
+            g_ms, g_Ss, g_mf, g_Sf, g_mp, g_Sp = (_f32c(g) for g in gouts)
+        else:
+            g_mf, g_Sf, g_mp, g_Sp = (_f32c(g) for g in gouts)
+            g_ms = g_Ss = None
+        need = ctx.needs_input_grad
+        need_q = slots.Q is not None or (Q is not None and need[7])
+        sink = _GradSink(call, packed, A, Bm, Cm, Q, slots, need_q)
+        g0 = S0 = None
+        if need[9]:
+            g0 = torch.empty(Bsz, n, device=Y.device, dtype=torch.float32)
+            sink.g.g_mu0 = g0.data_ptr()
+        if need[10]:
+            S0 = torch.empty(Bsz, n, n, device=Y.device, dtype=torch.float32)
+            sink.g.g_Sigma0 = S0.data_ptr()
+        ws = torch.empty(Bsz, T, 2 * (n + n * n), device=Y.device, dtype=torch.float32)
+        saved = _states(mf, Sf, mp, Sp, ms, Ss)
+        up = _states(g_mf, g_Sf, g_mp, g_Sp, g_ms, g_Ss)
+        call.lib.check(call.lib.dll.kvae_lgssm_smooth_bwd(C.byref(call.prob), C.byref(saved), C.byref(up),
+                                                          C.byref(sink.g), N.ptr(ws), int(with_rts), call.stream),
+                       "kvae_lgssm_smooth_bwd")
+        if g0 is not None and mu0.dim() == 1:
+            g0 = g0.sum(0)
+        if S0 is not None and Sigma0.dim() == 2:
+            S0 = S0.sum(0)
+        return (sink.gY if need[0] else None, sink.gU if need[1] else None, None, sink.gpacked,
+                sink.operand_grad("gA"), sink.operand_grad("gB"), sink.operand_grad("gC"),
+                sink.operand_grad("gQ") if need_q else None, None, g0, S0, None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# ELBO
+# ------------------------------------------------------------------------------------------------
+class LgssmElbo(torch.autograd.Function):
+    """The LGSSM terms of KalmanFilter.elbo (reference kalman_filter.py:347-389), summed over B and T.
+    Returns (total, per_term[4]); gradients are produced in the forward launch (unit upstream) and
+    scaled by the incoming scalar gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, mus, Sigs, eps, Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots):
+        call = _Call(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots)
+        Bsz, T, n, m, p = call.dims
+        dev = call.Y.device
+        mus_c = _f32c(mus.reshape(Bsz, T, n))
+        Sigs_c, eps_c = _f32c(Sigs), _f32c(eps)
+        terms = torch.empty(Bsz, T, 4, device=dev, dtype=torch.float32)
+        levels = torch.empty(2, device=dev, dtype=torch.int32)
+        want = any(ctx.needs_input_grad)
+        g_mus = g_Sigs = sink = None
+        if want:
+            need_q = slots.Q is not None or (Q is not None and ctx.needs_input_grad[10])
+            sink = _GradSink(call, packed, A, Bm, Cm, Q, slots, need_q)
+            g_mus, g_Sigs = torch.empty_like(mus_c), torch.empty_like(Sigs_c)
+            ctx.need_q = need_q
+        call.lib.check(call.lib.dll.kvae_lgssm_elbo(C.byref(call.prob), N.ptr(mus_c), N.ptr(Sigs_c), N.ptr(eps_c),
+                                                    N.ptr(terms), N.ptr(levels), N.ptr(g_mus), N.ptr(g_Sigs),
+                                                    C.byref(sink.g) if sink else None, call.stream),
+                       "kvae_lgssm_elbo")
+        per_term = terms.sum((0, 1))
+        ctx.sink, ctx.g_mus, ctx.g_Sigs, ctx.mus_shape = sink, g_mus, g_Sigs, mus.shape
+        ctx.chol_levels = levels
+        ctx.mark_non_differentiable(per_term)
+        return per_term.sum(), per_term
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        sink, need = ctx.sink, ctx.needs_input_grad
+        s = g_total
+        gp = sink.gpacked * s if sink.gpacked is not None else None
+        return ((ctx.g_mus * s).reshape(ctx.mus_shape) if need[0] else None,
+                ctx.g_Sigs * s if need[1] else None, None,
+                sink.gY * s if need[3] else None, sink.gU * s if need[4] else None, None, gp,
+                sink.operand_grad("gA", s), sink.operand_grad("gB", s), sink.operand_grad("gC", s),
+                sink.operand_grad("gQ", s) if ctx.need_q else None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# mixture-of-K dynamics
+# ------------------------------------------------------------------------------------------------
+class MixDynamics(torch.autograd.Function):
+    """record[b,t,:] = sum_k alpha[b,t,k] base[k,:]  (reference dyn_param.py:58-60,
+    switch_dyn_param.py:82-84), base = the K flattened matrices packed side by side."""
+
+    @staticmethod
+    def forward(ctx, alpha, base):
+        a, bs = _f32c(alpha), _f32c(base)
+        Bsz, T, K = a.shape
+        E = bs.shape[1]
+        out = torch.empty(Bsz, T, E, device=a.device, dtype=torch.float32)
+        lib = N.lib_for(a)
+        lib.check(lib.dll.kvae_mix_fwd(N.ptr(a), N.ptr(bs), N.ptr(out), Bsz * T, K, E, N.stream_for(a)), "kvae_mix_fwd")
+        ctx.save_for_backward(a, bs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        a, bs = ctx.saved_tensors
+        g = _f32c(g_out)
+        Bsz, T, K = a.shape
+        E = bs.shape[1]
+        lib = N.lib_for(a)
+        nblk = lib.dll.kvae_mix_bwd_partials(Bsz * T)
+        partials = torch.empty(nblk, K, E, device=a.device, dtype=torch.float32)
+        g_alpha, g_base = torch.empty_like(a), torch.empty_like(bs)
+        lib.check(lib.dll.kvae_mix_bwd(N.ptr(a), N.ptr(bs), N.ptr(g), N.ptr(g_alpha), N.ptr(g_base), N.ptr(partials),
+                                       Bsz * T, K, E, 0, N.stream_for(a)), "kvae_mix_bwd")
+        return g_alpha, g_base
+
+
+def mix_dynamics(alpha, mats):
+    """alpha [B,T,K]; mats: list of [K,r,c] parameters. Returns (record [B,T,E], offsets, views)."""
+    base = torch.cat([mt.reshape(mt.shape[0], -1) for mt in mats], dim=1)
+    rec = MixDynamics.apply(alpha, base)
+    offs, views, o = [], [], 0
+    for mt in mats:
+        e = mt.shape[1] * mt.shape[2]
+        offs.append(o)
+        views.append(rec[..., o:o + e].unflatten(-1, (mt.shape[1], mt.shape[2])))
+        o += e
+    return rec, offs, views

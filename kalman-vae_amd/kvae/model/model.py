@@ -1,0 +1,126 @@
+"""KVAE — drop-in for kvae.model.model.KVAE of the reference (model.py:11-301 there).
+
+Same constructor (`KVAE(config)`), sub-module names (encoder, decoder, kalman_filter[.dyn_params]),
+parameter registration order and state_dict keys, same `forward` / `compute_loss` / `impute`
+signatures and output dictionaries.  The conv VAE runs on PyTorch-ROCm; everything between
+`a_samples` and the LGSSM ELBO runs in the HIP kernels behind `self.kalman_filter`.
+"""
+import torch
+from torch import nn
+
+from kvae import noise
+from kvae.kalman import dyn_param as base_dyn_param
+from kvae.kalman import switch_dyn_param
+from kvae.kalman.kalman_filter import KalmanFilter
+from kvae.vae.losses import LinearScheduler, count_active_units, vae_loss
+from kvae.vae.vae import Decoder, Encoder
+
+
+class KVAE(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.encoder = Encoder(config)
+        self.decoder = Decoder(config)
+        self.scheduler = LinearScheduler(config)
+        self.beta = self.scheduler.get_beta(0) if config.scheduled_beta else 1.0
+        self.K, self.z_dim, self.a_dim, self.u_dim = config.num_modes, config.z_dim, config.a_dim, config.u_dim
+
+        # LGSSM initialisation: A_k = I, B_k, C_k ~ N(0, init_kf_matrices^2)  (reference model.py:33-45)
+        A0 = torch.eye(self.z_dim).repeat(self.K, 1, 1)
+        B0 = torch.randn(self.K, self.z_dim, self.u_dim) * config.init_kf_matrices
+        C0 = torch.randn(self.K, self.a_dim, self.z_dim) * config.init_kf_matrices
+        kind = config.dynamics_model.lower()
+        if kind == "switching":
+            prior = switch_dyn_param.StickyRegimePrior(self.K, p_stay=config.sticky_p_stay)
+            posterior = switch_dyn_param.MarkovVariationalRegimePosterior(
+                self.K, input_dim=self.a_dim, hidden_size=config.dynamics_hidden_dim)
+            Q0 = torch.eye(self.z_dim).repeat(self.K, 1, 1) * config.noise_transition
+            dynamics = switch_dyn_param.SwitchingDynamicsParameter(
+                A0, B0, C0, Q=Q0, prior=prior, hidden_lstm=config.dynamics_hidden_dim,
+                markov_regime_posterior=posterior)
+            dynamics.tau = config.tau_init
+        elif kind == "lstm":
+            dynamics = base_dyn_param.DynamicsParameter(A0, B0, C0, hidden_lstm=config.dynamics_hidden_dim)
+        else:
+            raise ValueError(f"Unknown dynamics model: {config.dynamics_model}")
+        # config noise values are variances
+        self.kalman_filter = KalmanFilter(config.noise_transition ** 0.5, config.noise_emission ** 0.5,
+                                          torch.zeros(self.z_dim), torch.eye(self.z_dim) * config.init_cov, dynamics)
+
+    # -- VAE halves -----------------------------------------------------------------------------
+    def reparameterize(self, mu, var):
+        std = torch.sqrt(var + 1e-6)
+        eps = noise.take("eps_a")
+        eps = torch.randn_like(std) if eps is None else eps.to(device=std.device, dtype=std.dtype).reshape(std.shape)
+        return mu + eps * std
+
+    def encode_sequence(self, x):
+        lead = x.shape[:2]
+        mu, var = self.encoder(x.flatten(0, 1))
+        a = self.reparameterize(mu, var)
+        return a.unflatten(0, lead), mu.unflatten(0, lead), var.unflatten(0, lead)
+
+    def decode_sequence(self, a):
+        return self.decoder(a.flatten(0, 1)).unflatten(0, a.shape[:2])
+
+    def _to_pixels(self, logits):
+        return torch.sigmoid(logits) if self.config.out_distr.lower() == "bernoulli" else logits
+
+    # -- full pass ------------------------------------------------------------------------------
+    def forward(self, x, u=None, mask=None):
+        a_samples, a_mu, a_var = self.encode_sequence(x)
+        if u is None:
+            u = torch.zeros(x.shape[0], x.shape[1], self.u_dim, device=x.device, dtype=x.dtype)
+        self.kalman_filter.dyn_params.reset_state()
+        (mus_smooth, Sigmas_smooth, mus_filt, Sigmas_filt, mus_pred, Sigmas_pred,
+         A_list, B_list, C_list) = self.kalman_filter.smooth(a_samples, u, mask=mask)
+        x_logits = self.decode_sequence(a_samples)
+        return {
+            "x_recon": self._to_pixels(x_logits), "x_logits": x_logits,
+            "a_samples": a_samples, "a_mu": a_mu, "a_var": a_var,
+            "mus_smooth": mus_smooth, "Sigmas_smooth": Sigmas_smooth,
+            "mus_filt": mus_filt, "Sigmas_filt": Sigmas_filt,
+            "mus_pred": mus_pred, "Sigmas_pred": Sigmas_pred,
+            "ABC": (A_list, B_list, C_list), "u": u,
+            "state_probs": self.kalman_filter.dyn_params.state_seq,
+        }
+
+    def compute_loss(self, x, outputs, kf_weight=1.0, vae_weight=1.0, mask=None, with_metrics=True):
+        """`with_metrics=False` (addition over the reference) skips the three host syncs of the
+        active-unit statistics so that the step can be captured into a hipGraph."""
+        B, T = x.shape[:2]
+        a, a_mu, a_var = outputs["a_samples"], outputs["a_mu"], outputs["a_var"]
+        A_list, B_list, C_list = outputs["ABC"]
+        u = outputs.get("u")
+        if u is None:
+            u = torch.zeros(B, T, self.u_dim, device=x.device, dtype=x.dtype)
+        x_mu = outputs.get("x_logits", outputs["x_recon"])
+        x_var = torch.tensor(self.config.noise_pixel_var, device=x.device, dtype=x_mu.dtype) \
+            if self.config.out_distr.lower() != "bernoulli" else None
+        vae_elbo, recon, reg = vae_loss(x, x_mu, x_var, a, a_mu, a_var,
+                                        scale_reconstruction=self.config.scale_reconstruction, mask=mask,
+                                        out_distr=self.config.out_distr, beta=self.beta)
+        elbo_kf = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u,
+                                          A_list, B_list, C_list, mask=mask)
+        elbo_total = vae_weight * vae_elbo + kf_weight * elbo_kf
+        out = {"loss": -elbo_total, "elbo_total": elbo_total, "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
+               "recon": recon, "kl": reg}
+        if with_metrics:
+            active, variances = count_active_units(a_mu)
+            out.update(active_units=active, latent_var_0=variances[0].item(), latent_var_1=variances[1].item())
+        return out
+
+    @torch.no_grad()
+    def impute(self, x, mask, u=None):
+        """Eval-mode imputation: decode C_t mu_{t|T} (smoothed) and C_t mu_{t|t} (filtered)."""
+        self.eval()
+        mask = mask.to(device=x.device, dtype=x.dtype)
+        out = self.forward(x, u=u, mask=mask)
+        _, _, C_list = out["ABC"]
+        a_imputed = (C_list @ out["mus_smooth"]).squeeze(-1)
+        a_filtered = (C_list @ out["mus_filt"]).squeeze(-1)
+        dec = lambda a: self._to_pixels(self.decode_sequence(a))
+        return {"x_recon": dec(out["a_samples"]), "x_imputed": dec(a_imputed), "x_filtered": dec(a_filtered),
+                "a_vae": out["a_samples"], "a_imputed": a_imputed, "a_filtered": a_filtered,
+                "state_probs": out["state_probs"]}

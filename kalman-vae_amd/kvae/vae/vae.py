@@ -1,0 +1,110 @@
+"""Conv VAE encoder / decoder of the KVAE.  These run on PyTorch-ROCm (MIOpen convolutions) by
+design — the north-star scope keeps them out of the hand-written HIP path — and are re-declared
+here only so that state_dict keys and shapes match the reference (kvae/vae/vae.py:11-116):
+    encoder.conv_layers.{0,2,4}, encoder.fc_mu, encoder.fc_var.0, decoder.fc, decoder.deconv_layers.{0,3,6}
+"""
+import os
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from kvae.utils.config import KVAEConfig
+
+
+def _conv_out(size, k, s, p):
+    return (size + 2 * p - k) // s + 1
+
+
+class Encoder(nn.Module):
+    """x [N,C,H,W] -> (mu [N,a], var [N,a]) with var = noise_emission * sigmoid(.)."""
+
+    def __init__(self, config: KVAEConfig):
+        super().__init__()
+        self.config = config
+        blocks, c_in, side = [], config.img_channels, config.img_size
+        for c_out in config.encoder_channels:
+            blocks += [nn.Conv2d(c_in, c_out, config.encoder_kernel_size, config.encoder_stride,
+                                 config.encoder_padding), nn.ReLU()]
+            side = _conv_out(side, config.encoder_kernel_size, config.encoder_stride, config.encoder_padding)
+            c_in = c_out
+        self.conv_layers = nn.Sequential(*blocks)
+        self.flat_size = c_in * side * side
+        self.fc_mu = nn.Linear(self.flat_size, config.a_dim)
+        self.fc_var = nn.Sequential(nn.Linear(self.flat_size, config.a_dim), nn.Sigmoid())
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        feat = self.conv_layers(x).flatten(1)
+        return self.fc_mu(feat), self.config.noise_emission * self.fc_var(feat)
+
+
+class Decoder(nn.Module):
+    """a [N,a] -> logits/means [N,C,H,W]: fc -> [c0,s,s] -> (conv3x3 -> PixelShuffle(2) -> ReLU)* -> conv -> PS."""
+
+    def __init__(self, config: KVAEConfig):
+        super().__init__()
+        self.config = config
+        chans = list(config.decoder_channels)
+        self.init_size = config.img_size // (2 ** len(chans))
+        self.init_channels = chans[0]
+        self.fc = nn.Linear(config.a_dim, self.init_channels * self.init_size ** 2)
+        up = []
+        for c_in, c_out in zip(chans[:-1], chans[1:]):
+            up += [nn.Conv2d(c_in, 4 * c_out, kernel_size=3, padding=1), nn.PixelShuffle(2), nn.ReLU()]
+        up += [nn.Conv2d(chans[-1], 4 * config.img_channels, kernel_size=3, padding=1), nn.PixelShuffle(2)]
+        self.deconv_layers = nn.Sequential(*up)
+
+    def forward(self, a: torch.Tensor) -> torch.Tensor:
+        h = self.fc(a).unflatten(1, (self.init_channels, self.init_size, self.init_size))
+        return self.deconv_layers(h)
+
+
+class VAE(nn.Module):
+    """Frame-wise VAE wrapper (reference kvae/vae/vae.py:119-242): same method names and output keys."""
+
+    def __init__(self, config: KVAEConfig):
+        super().__init__()
+        self.config = config
+        self.encoder = Encoder(config)
+        self.decoder = Decoder(config)
+
+    def encode(self, x):
+        return self.encoder(x)
+
+    def decode(self, a):
+        return self.decoder(a)
+
+    def reparameterize(self, mu, var):
+        return mu + torch.randn_like(var) * var.sqrt()
+
+    def forward(self, x: torch.Tensor) -> dict:
+        lead = x.shape[:2]
+        mu, var = self.encode(x.flatten(0, 1))
+        a = self.reparameterize(mu, var)
+        x_mu = self.decode(a)
+        x_rec = torch.sigmoid(x_mu) if self.config.out_distr.lower() == "bernoulli" else x_mu
+        back = lambda t: t.unflatten(0, lead)
+        return {"x_recon": back(x_rec), "x_recon_mu": back(x_mu),
+                "x_recon_var": torch.tensor(self.config.noise_pixel_var, device=x.device, dtype=x_mu.dtype),
+                "a_vae": back(a), "a_mu": back(mu), "a_var": back(var)}
+
+    def sample_from_prior(self, n: int = 1, device=None) -> torch.Tensor:
+        device = device or next(self.parameters()).device
+        return self.decode(torch.randn(n, self.config.a_dim, device=device))
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, config: KVAEConfig = None, device: str = "cpu"):
+        """Accepts a plain state_dict or a {'state_dict': ...} / {'model_state': ...} payload; only
+        tensors are unpickled (weights_only=True)."""
+        if not os.path.exists(checkpoint_path):
+            raise FileNotFoundError(checkpoint_path)
+        vae = cls(config or KVAEConfig())
+        payload = torch.load(checkpoint_path, map_location=device, weights_only=True)
+        for key in ("state_dict", "model_state"):
+            if isinstance(payload, dict) and key in payload:
+                payload = payload[key]
+        for part in ("encoder", "decoder"):
+            sub = {k.split(part + ".", 1)[1]: v for k, v in payload.items() if (part + ".") in k}
+            if sub:
+                getattr(vae, part).load_state_dict(sub)
+        return vae.to(device)

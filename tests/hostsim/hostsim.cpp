@@ -1,0 +1,146 @@
+// hostsim.cpp — TEST-ONLY host build of the kernel bodies in kalman-vae_amd/csrc/*.h.
+//
+// Compiles the very same body headers with KVAE_HOSTSIM (KV_PAR = serial loop, KV_SYNC = no-op) and
+// exports the C ABI of include/kvae_lgssm.h over HOST pointers, one "wavefront" at a time.  It lets
+// the CPU-only test tier (a) run every kernel's arithmetic against the oracle and the goldens and
+// (b) run it under -fsanitize=address,undefined (GPU sanitizers are unavailable on the pool).
+// It is never loaded by the product package (kalman-vae_amd/kvae/_native.py loads only the gfx950
+// library and raises if that is missing).
+#define KVAE_HOSTSIM 1
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+
+#include "../../kalman-vae_amd/csrc/lgssm_bwd.h"
+#include "../../kalman-vae_amd/csrc/lgssm_elbo.h"
+#include "../../kalman-vae_amd/csrc/lgssm_fwd.h"
+#include "../../kalman-vae_amd/csrc/mix.h"
+
+using namespace kvae;
+
+static int check_problem(const kvae_lgssm_problem *p) {
+  if (!p) return KVAE_ERR_NULL;
+  if (p->B < 1 || p->T < 1 || p->n < 1 || p->m < 1 || p->p < 1 || p->n > KVAE_MAX_DIM || p->m > KVAE_MAX_DIM ||
+      p->p > KVAE_MAX_DIM)
+    return KVAE_ERR_DIMS;
+  if (!p->A.ptr || !p->Bm.ptr || !p->C.ptr || !p->Q.ptr || !p->R || !p->mu0 || !p->Sigma0 || !p->Y || !p->U)
+    return KVAE_ERR_NULL;
+  return KVAE_OK;
+}
+
+#define KVAE_DISPATCH(P, CALL)                              \
+  do {                                                      \
+    if ((P).n == 4 && (P).m == 4 && (P).p == 2) {          \
+      using D = SDims<4, 4, 2>;                             \
+      CALL;                                                 \
+    } else if ((P).n == 16 && (P).m == 16 && (P).p == 2) { \
+      using D = SDims<16, 16, 2>;                           \
+      CALL;                                                 \
+    } else {                                                \
+      using D = RDims;                                      \
+      CALL;                                                 \
+    }                                                       \
+  } while (0)
+
+template <class D>
+static void run_fwd(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, int do_filter, int do_rts) {
+  auto L = std::make_unique<FwdLds<D>>();
+  const D d(P.n, P.m, P.p);
+  for (int b = 0; b < P.B; ++b) {
+    memset(L.get(), 0xFF, sizeof(*L));  // poison: NaNs expose reads of unwritten scratch
+    if (do_filter) filter_sweep(d, P, S, b, *L);
+    if (do_rts) rts_sweep(d, P, S, b, *L);
+  }
+}
+
+template <class D>
+static void run_bwd(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                    const kvae_lgssm_input_grads &G, float *ws, int with_rts) {
+  auto L = std::make_unique<BwdLds<D>>();
+  const D d(P.n, P.m, P.p);
+  for (int b = 0; b < P.B; ++b) {
+    memset(L.get(), 0xFF, sizeof(*L));
+    if (with_rts)
+      rts_bwd_sweep(d, P, S, U, G, ws, b, *L);
+    else
+      filter_bwd_seed(d, P, U, G, ws, b);
+    filter_bwd_sweep(d, P, S, G, ws, b, *L);
+  }
+}
+
+template <class D>
+static void run_elbo(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps, float *terms,
+                     int32_t *levels, float *g_mus, float *g_Sigs, const kvae_lgssm_input_grads *g) {
+  auto L = std::make_unique<ElboLds<D>>();
+  const D d(P.n, P.m, P.p);
+  levels[0] = levels[1] = 0;
+  for (int b = 0; b < P.B; ++b)
+    for (int t = 0; t < P.T; ++t) {
+      memset(L.get(), 0xFF, sizeof(*L));
+      elbo_probe_body(d, P, Sigs, levels, b, t, *L);
+    }
+  for (int b = 0; b < P.B; ++b)
+    for (int t = 0; t < P.T; ++t) {
+      memset(L.get(), 0xFF, sizeof(*L));
+      elbo_body(d, P, mus, Sigs, eps, terms, levels, g_mus, g_Sigs, g, b, t, *L);
+    }
+}
+
+extern "C" {
+
+static int fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int do_filter, int do_rts) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!st || !st->mus_filt || !st->Sigmas_filt || !st->mus_pred || !st->Sigmas_pred) return KVAE_ERR_NULL;
+  if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
+  KVAE_DISPATCH(*prob, (run_fwd<D>(*prob, *st, do_filter, do_rts)));
+  return KVAE_OK;
+}
+int kvae_lgssm_filter_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *) { return fwd(prob, out, 1, 0); }
+int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *io, void *) { return fwd(prob, io, 0, 1); }
+int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *) { return fwd(prob, out, 1, 1); }
+
+int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                          const kvae_lgssm_input_grads *out, float *ws, int with_rts, void *) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!saved || !up || !out || !ws) return KVAE_ERR_NULL;
+  if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
+  KVAE_DISPATCH(*prob, (run_bwd<D>(*prob, *saved, *up, *out, ws, with_rts)));
+  return KVAE_OK;
+}
+
+int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth, const float *eps,
+                    float *terms, int32_t *chol_levels, float *g_mus, float *g_Sigmas, const kvae_lgssm_input_grads *g,
+                    void *) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!mus_smooth || !Sigmas_smooth || !eps || !terms || !chol_levels) return KVAE_ERR_NULL;
+  if (g_mus && (!g_Sigmas || !g || !g->gA.ptr || !g->gB.ptr || !g->gC.ptr || !g->gY)) return KVAE_ERR_NULL;
+  KVAE_DISPATCH(*prob, (run_elbo<D>(*prob, mus_smooth, Sigmas_smooth, eps, terms, chol_levels, g_mus, g_Sigmas, g)));
+  return KVAE_OK;
+}
+
+int kvae_mix_fwd(const float *alpha, const float *base, float *out, int64_t rows, int32_t K, int32_t E, void *) {
+  if (!alpha || !base || !out) return KVAE_ERR_NULL;
+  if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
+  for (int64_t i = 0; i < rows * E; ++i) mix_fwd_elem(alpha, base, out, i, K, E);
+  return KVAE_OK;
+}
+int64_t kvae_mix_bwd_partials(int64_t rows) { return (rows + KVAE_MIX_ROWS_PER_BLOCK - 1) / KVAE_MIX_ROWS_PER_BLOCK; }
+int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, float *g_alpha, float *g_base, float *partials,
+                 int64_t rows, int32_t K, int32_t E, int32_t accumulate_alpha, void *) {
+  if (!alpha || !base || !g_out || !g_alpha || !g_base || !partials) return KVAE_ERR_NULL;
+  if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
+  for (int64_t i = 0; i < rows * K; ++i) mix_bwd_alpha_elem(base, g_out, g_alpha, i, K, E, accumulate_alpha);
+  const int64_t nblk = kvae_mix_bwd_partials(rows);
+  for (int64_t blk = 0; blk < nblk; ++blk)
+    for (int e = 0; e < E; ++e) mix_bwd_partial_elem(alpha, g_out, partials, blk, e, rows, K, E);
+  for (int i = 0; i < K * E; ++i) mix_bwd_final_elem(partials, g_base, i, nblk, K * E);
+  return KVAE_OK;
+}
+int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
+const char *kvae_last_error(void) { return ""; }
+const char *kvae_build_info(void) { return "kvae_lgssm HOSTSIM (test-only host build of the kernel bodies)"; }
+}

@@ -1,0 +1,111 @@
+"""CPU tier: run the product op layer (kvae.kalman.*, autograd Functions, ctypes structs) against the
+HOST SIMULATION of the kernel bodies (tests/hostsim) and compare with the goldens captured from the
+reference.  This checks the kernel arithmetic, the hand-derived backward and the host logic without
+a GPU; the same comparisons run against the real gfx950 library in tests/test_gpu_parity.py."""
+import pytest
+import torch
+
+from golden_util import LATENT_CASES, SMOOTH_KEYS, load, rel_err, sub
+from hostsim.build import build as build_hostsim
+
+torch.set_num_threads(4)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hostsim_backend():
+    from kvae import _native
+    lib = _native.LgssmLib(build_hostsim())
+    _native._set_test_backend(lib)
+    yield lib
+    _native._set_test_backend(None)
+
+
+def make_filter(g, kind, device="cpu"):
+    """Product KalmanFilter + dynamics module carrying the golden's parameters."""
+    from kvae.model.model import KVAE
+    from kvae.utils.config import KVAEConfig
+    dyn = sub(g, "dyn.")
+    K, n = dyn["A"].shape[0], dyn["A"].shape[1]
+    model = KVAE(KVAEConfig(dynamics_model=kind, num_modes=K, z_dim=n))
+    kf = model.kalman_filter
+    missing = kf.dyn_params.load_state_dict(dyn, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    kf.load_state_dict({"Q": g["Qbuf"], "R": g["R"], "mu0": g["mu0"], "Sigma0": g["Sigma0"]}, strict=False)
+    if "tau" in g and hasattr(kf.dyn_params, "tau"):
+        kf.dyn_params.tau = float(g["tau"])
+    kf.train(bool(g["train"]))
+    return kf.to(device)
+
+
+def run_latent(kf, g, device="cpu"):
+    from kvae import noise
+    a = g["a"].to(device).clone().requires_grad_(True)
+    u, mask = g["u"].to(device), g["mask"].to(device)
+    kf.dyn_params.reset_state()
+    with noise.inject(eps_z=g["eps_z"], gumbel=g.get("gumbel")):
+        outs = kf.smooth(a, u, mask=None if bool((mask == 1).all()) else mask)
+        elbo = kf.elbo(outs[0], outs[1], a, u, outs[6], outs[7], outs[8], mask=mask)
+    return a, outs, elbo
+
+
+def check_latent(kf, g, a, outs, elbo, name, tol_scale=1.0):
+    tol = (5e-5 if "z16" in name else 1e-5) * tol_scale
+    if name == "stress_switch_z16_B2_T200":
+        tol = 2e-3  # fp32 error budget of this case, see tests/test_oracle_golden.py
+    for k, v in zip(SMOOTH_KEYS, outs):
+        if k in g:
+            assert rel_err(v.cpu(), g[k]) < tol, k
+        elif k + "_every8" in g:
+            assert rel_err(v.cpu()[:, ::8], g[k + "_every8"]) < tol, k
+    assert rel_err(kf.dyn_params.state_seq.cpu(), g["state_seq"]) < tol
+    assert rel_err(elbo.cpu(), g["elbo"]) < max(tol, 2e-5), "elbo"
+    if "grad.a" not in g:
+        return
+    params = dict(kf.dyn_params.named_parameters())
+    grads = torch.autograd.grad(-elbo, [a] + list(params.values()), allow_unused=True)
+    gtol = 20 * tol
+    assert rel_err(grads[0].cpu(), g["grad.a"]) < gtol, "grad.a"
+    for (k, p), gr in zip(params.items(), grads[1:]):
+        ref = g["grad.dyn." + k]
+        gr = torch.zeros_like(ref) if gr is None else gr.cpu()
+        if ref.abs().max() < 1e-12:
+            assert gr.abs().max() < 1e-9, k
+        else:
+            assert rel_err(gr, ref) < gtol, k
+
+
+@pytest.mark.parametrize("name,kind", LATENT_CASES)
+def test_latent_hostsim(name, kind):
+    g = load(name)
+    kf = make_filter(g, kind)
+    a, outs, elbo = run_latent(kf, g)
+    check_latent(kf, g, a, outs, elbo, name)
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_rocket_hostsim(batch):
+    """n=2, m=1, p=1: the run-time-dimension instantiation of the kernels."""
+    from kvae import noise
+    from kvae.kalman.kalman_filter import KalmanFilter
+    from kvae.kalman.switch_dyn_param import SwitchingDynamicsParameter
+    g = load(f"rocket_B{batch}")
+    dyn = SwitchingDynamicsParameter(g["A"], g["B"], g["C"])
+    kf = KalmanFilter(2.0, 4.0, g["mu0"], g["Sigma0"], dyn)
+    with torch.no_grad(), noise.inject(eps_z=g["eps_z"]):
+        outs = kf.smooth(g["Y"], g["U"])
+        elbo = kf.elbo(outs[0], outs[1], g["Y"], g["U"], outs[6], outs[7], outs[8])
+    for k, v in zip(SMOOTH_KEYS, outs):
+        assert rel_err(v, g[k]) < 2e-5, k
+    assert rel_err(elbo, g["elbo"]) < 2e-5
+
+
+def test_no_cpu_fallback():
+    """Without the injected simulator the product refuses host tensors."""
+    from kvae import _native
+    saved = _native._test_backend
+    _native._set_test_backend(None)
+    try:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            _native.lib_for(torch.zeros(1))
+    finally:
+        _native._set_test_backend(saved)

@@ -95,3 +95,50 @@ def test_train_step(name, kind):
             # Adam's first update is lr*g/(|g|+1e-8): entries whose gradient is O(1e-8) are rounding-
             # sensitive, hence 1e-3 (of max|param|) here while gradients themselves are held to 2e-4
             assert rel_err(tr.sd[k].detach(), g["after." + k]) < 1e-3, k
+
+
+# ---- the C restatement (oracle/lgssm_oracle.c) against the same goldens ---------------------------
+@pytest.mark.parametrize("name,kind", [c for c in LATENT_CASES if "K3_B4_T50" in c[0] or "z16" in c[0]
+                                       or "masked_switch" in c[0] or "T12_u" in c[0]])
+def test_c_oracle_latent(name, kind):
+    from oracle import c_oracle
+    g = load(name)
+    have_all = all(k in g for k in ("A_list", "B_list", "C_list"))
+    if not have_all:  # slim fixture: rebuild the per-step stacks with the torch oracle
+        dyn = sub(g, "dyn.")
+        o = O.lgssm_filter(g["a"], g["u"], g["mask"], dyn, kind, g["Qbuf"], g["R"], g["mu0"], g["Sigma0"],
+                           tau=float(g["tau"]), is_training=bool(g["train"]), gumbel=g.get("gumbel"),
+                           trans_matrix=g.get("trans_matrix"))
+        A, Bm, Cm, Q = o["A_list"], o["B_list"], o["C_list"], o.get("Q_seq", g["Qbuf"])
+    else:
+        A, Bm, Cm, Q = g["A_list"], g["B_list"], g["C_list"], g.get("Q_seq", g["Qbuf"])
+    out = c_oracle.smooth(g["a"], g["u"], g["mask"], A, Bm, Cm, Q, g["R"], g["mu0"], g["Sigma0"])
+    tol = 2e-3 if name == "stress_switch_z16_B2_T200" else (5e-5 if "z16" in name else 1e-5)
+    for k in ("mus_smooth", "mus_filt", "mus_pred"):
+        assert rel_err(out[k].unsqueeze(-1), g[k]) < tol, k
+    for k in ("Sigmas_smooth", "Sigmas_filt", "Sigmas_pred"):
+        if k in g:
+            assert rel_err(out[k], g[k]) < tol, k
+        else:
+            assert rel_err(out[k][:, ::8], g[k + "_every8"]) < tol, k
+    terms, levels = c_oracle.elbo_terms(out["mus_smooth"], out["Sigmas_smooth"], g["eps_z"], g["a"], g["u"], g["mask"],
+                                        A, Bm, Cm, Q, g["R"], g["mu0"], g["Sigma0"])
+    total = terms.sum()
+    if "log_qseq" in g:
+        total += float(g["log_pseq"].double().sum() - g["log_qseq"].double().sum())
+    elbo = total / max(float(g["mask"].sum()), 1.0)
+    assert abs(elbo - float(g["elbo"])) <= max(tol, 3e-5) * abs(float(g["elbo"])), (elbo, float(g["elbo"]))
+    assert list(levels) == [0, 0]
+
+
+def test_c_oracle_rocket():
+    from oracle import c_oracle
+    g = load("rocket_B4")
+    out = c_oracle.smooth(g["Y"], g["U"], None, g["A"][0], g["B"][0], g["C"][0], g["Qk"][0], g["R"], g["mu0"], g["Sigma0"])
+    for k in ("mus_smooth", "mus_filt", "mus_pred"):
+        assert rel_err(out[k].unsqueeze(-1), g[k]) < 2e-5, k
+    for k in ("Sigmas_smooth", "Sigmas_filt", "Sigmas_pred"):
+        assert rel_err(out[k], g[k]) < 2e-5, k
+    terms, _ = c_oracle.elbo_terms(out["mus_smooth"], out["Sigmas_smooth"], g["eps_z"], g["Y"], g["U"], None,
+                                   g["A"][0], g["B"][0], g["C"][0], g["Qk"][0], g["R"], g["mu0"], g["Sigma0"])
+    assert abs(terms.sum() / g["Y"].shape[0] / g["Y"].shape[1] - float(g["elbo"])) < 2e-5 * abs(float(g["elbo"]))
