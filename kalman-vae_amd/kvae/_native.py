@@ -129,3 +129,31 @@ def stream_for(t: torch.Tensor):
 
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---- optional per-call HIP-event timing (bench.py's roofline leg) -----------------------------------
+_prof = None
+
+
+def profile_start():
+    global _prof
+    _prof = {}
+
+
+def profile_stop():
+    """{call name: [milliseconds per call]} measured with HIP events on the launch stream."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return {k: [s.elapsed_time(e) for s, e in v] for k, v in (rec or {}).items()}
+
+
+def timed(name, t, thunk):
+    if _prof is None or not t.is_cuda:
+        return thunk()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = thunk()
+    e.record()
+    _prof.setdefault(name, []).append((s, e))
+    return rc

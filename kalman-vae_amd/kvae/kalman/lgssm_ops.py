@@ -140,7 +140,8 @@ class LgssmSmooth(torch.autograd.Function):
         ms, Ss = (mk(Bsz, T, n), mk(Bsz, T, n, n)) if with_rts else (None, None)
         st = _states(mf, Sf, mp, Sp, ms, Ss)
         fn = call.lib.dll.kvae_lgssm_smooth_fwd if with_rts else call.lib.dll.kvae_lgssm_filter_fwd
-        call.lib.check(fn(C.byref(call.prob), C.byref(st), call.stream), "kvae_lgssm_smooth_fwd")
+        call.lib.check(N.timed("smooth_fwd" if with_rts else "filter_fwd", call.Y,
+                               lambda: fn(C.byref(call.prob), C.byref(st), call.stream)), "kvae_lgssm_smooth_fwd")
         ctx.slots, ctx.with_rts = slots, with_rts
         ctx.save_for_backward(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss)
         if with_rts:
@@ -171,9 +172,9 @@ class LgssmSmooth(torch.autograd.Function):
         ws = torch.empty(Bsz, T, 2 * (n + n * n), device=Y.device, dtype=torch.float32)
         saved = _states(mf, Sf, mp, Sp, ms, Ss)
         up = _states(g_mf, g_Sf, g_mp, g_Sp, g_ms, g_Ss)
-        call.lib.check(call.lib.dll.kvae_lgssm_smooth_bwd(C.byref(call.prob), C.byref(saved), C.byref(up),
-                                                          C.byref(sink.g), N.ptr(ws), int(with_rts), call.stream),
-                       "kvae_lgssm_smooth_bwd")
+        call.lib.check(N.timed("smooth_bwd", call.Y, lambda: call.lib.dll.kvae_lgssm_smooth_bwd(
+            C.byref(call.prob), C.byref(saved), C.byref(up), C.byref(sink.g), N.ptr(ws), int(with_rts), call.stream)),
+            "kvae_lgssm_smooth_bwd")
         if g0 is not None and mu0.dim() == 1:
             g0 = g0.sum(0)
         if S0 is not None and Sigma0.dim() == 2:
@@ -207,10 +208,9 @@ class LgssmElbo(torch.autograd.Function):
             sink = _GradSink(call, packed, A, Bm, Cm, Q, slots, need_q)
             g_mus, g_Sigs = torch.empty_like(mus_c), torch.empty_like(Sigs_c)
             ctx.need_q = need_q
-        call.lib.check(call.lib.dll.kvae_lgssm_elbo(C.byref(call.prob), N.ptr(mus_c), N.ptr(Sigs_c), N.ptr(eps_c),
-                                                    N.ptr(terms), N.ptr(levels), N.ptr(g_mus), N.ptr(g_Sigs),
-                                                    C.byref(sink.g) if sink else None, call.stream),
-                       "kvae_lgssm_elbo")
+        call.lib.check(N.timed("elbo", call.Y, lambda: call.lib.dll.kvae_lgssm_elbo(
+            C.byref(call.prob), N.ptr(mus_c), N.ptr(Sigs_c), N.ptr(eps_c), N.ptr(terms), N.ptr(levels), N.ptr(g_mus),
+            N.ptr(g_Sigs), C.byref(sink.g) if sink else None, call.stream)), "kvae_lgssm_elbo")
         per_term = terms.sum((0, 1))
         ctx.sink, ctx.g_mus, ctx.g_Sigs, ctx.mus_shape = sink, g_mus, g_Sigs, mus.shape
         ctx.chol_levels = levels

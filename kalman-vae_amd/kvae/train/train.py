@@ -1,0 +1,136 @@
+"""Training step of the KVAE on MI355X: the body of the reference's train_one_epoch
+(kvae/train/train.py:32-62 there: zero_grad, forward, compute_loss, backward, clip_grad_norm_(10),
+Adam.step) restated for one process per GPU.
+
+  * gradients of all parameters live in ONE flat fp32 buffer (each p.grad is a view), so gradient
+    clipping is two kernels and data-parallel training needs exactly ONE RCCL all-reduce per step
+    (~0.45 MB, latency-bound on xGMI: a single bucket, no overlap machinery);
+  * the whole step (convs on MIOpen, LSTM, the HIP LGSSM chain, loss, backward, clip, fused Adam) is
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; with >1 rank the graph is cut
+    around the all-reduce;
+  * no host synchronisation inside a step: losses stay on the device until the caller reads them
+    (the reference forces six device->host syncs per step).
+Equal shards + mask == 1 make the mean of per-rank gradients the global-batch gradient (the ELBO is
+normalised by the local frame count, kalman_filter.py:392 / losses.py:82).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Trainer:
+    def __init__(self, model, lr=7e-3, weight_decay=0.0, grad_clip_norm=10.0, kf_weight=1.0, vae_weight=1.0,
+                 use_graph=True, world_size=1):
+        self.model, self.clip = model, grad_clip_norm
+        self.kf_weight, self.vae_weight = kf_weight, vae_weight
+        self.world = world_size
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        on_gpu = dev.type == "cuda"
+        self.opt = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
+        self.use_graph = bool(use_graph) and on_gpu
+        self.graph_fb = self.graph_opt = None
+        self.static_x = None
+        self.out = {}
+
+    # -- the three segments of a step ---------------------------------------------------------------
+    def _forward_backward(self, x):
+        self.flat_grad.zero_()
+        self.model.kalman_filter.dyn_params.reset_state()
+        outputs = self.model(x, mask=None)          # all frames observed == mask of ones (train.py:41)
+        losses = self.model.compute_loss(x, outputs, kf_weight=self.kf_weight, vae_weight=self.vae_weight, mask=None,
+                                         with_metrics=False)
+        losses["loss"].backward()
+        self.out = {k: losses[k].detach() for k in ("loss", "elbo_kf", "elbo_vae_total")}
+
+    def _allreduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat_grad)
+            self.flat_grad.div_(self.world)
+
+    def _clip_and_update(self):
+        if self.clip and self.clip > 0:   # torch.nn.utils.clip_grad_norm_ on the flat view of all grads
+            total = torch.linalg.vector_norm(self.flat_grad)
+            self.flat_grad.mul_(torch.clamp(self.clip / (total + 1e-6), max=1.0))
+            self.out["grad_norm"] = total
+        self.opt.step()
+
+    # -- public ---------------------------------------------------------------------------------------
+    def step(self, x):
+        """One optimisation step on batch x [B,T,C,H,W] (already on the device). Returns device scalars."""
+        if not self.use_graph:
+            self._forward_backward(x)
+            self._allreduce()
+            self._clip_and_update()
+            return self.out
+        if self.graph_fb is None:
+            self._capture(x)
+        self.static_x.copy_(x, non_blocking=True)
+        self.graph_fb.replay()
+        if self.world > 1:
+            self._allreduce()
+            self.graph_opt.replay()
+        return self.out
+
+    def _capture(self, x):
+        self.static_x = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up outside capture (MIOpen find, allocator, Adam state)
+            for _ in range(3):
+                self._forward_backward(self.static_x)
+                self._allreduce()
+                self._clip_and_update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_fb = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(self.graph_fb):
+                self._forward_backward(self.static_x)
+                self._clip_and_update()
+        else:
+            with torch.cuda.graph(self.graph_fb):
+                self._forward_backward(self.static_x)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
+                self._clip_and_update()
+
+
+def init_distributed():
+    """One process per GPU; RCCL ('nccl' on ROCm) over xGMI. Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl" if dev.type == "cuda" else "gloo", rank=rank, world_size=world)
+    return rank, world, dev
+
+
+def train_one_epoch(trainer, loader, device, epoch=None):
+    """Reference-shaped epoch loop (train.py:23-76): returns mean loss / elbo_kf / elbo_vae_total."""
+    model = trainer.model
+    model.train()
+    if model.config.scheduled_beta and epoch is not None:
+        model.beta = model.scheduler.get_beta(epoch)
+    sums, n = None, 0
+    for batch in loader:
+        x = batch["images"].float().to(device, non_blocking=True)
+        out = trainer.step(x)
+        vals = torch.stack([out["loss"], out["elbo_kf"], out["elbo_vae_total"]])
+        sums = vals.clone() if sums is None else sums + vals
+        n += 1
+    sums = (sums / max(n, 1)).tolist() if sums is not None else [0.0, 0.0, 0.0]
+    return {"loss": sums[0], "elbo_kf": sums[1], "elbo_vae_total": sums[2]}

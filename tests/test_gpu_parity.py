@@ -1,0 +1,150 @@
+"""GPU tier (-m gpu): the gfx950 library against the goldens captured from the reference, against the
+CPU oracle on seeded inputs, and at BASELINE config sizes.  Every call goes through the C ABI of
+include/kvae_lgssm.h (ctypes -> libkvae_lgssm.so); nothing here can pass on a CPU fallback because
+the product has none (test_native_loaded asserts the HIP library is the one mapped in)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from golden_util import LATENT_CASES, SMOOTH_KEYS, load, rel_err, stability_state_dict, sub
+import parity_cases
+from parity_cases import _random_problem
+from test_hostsim_ops import check_latent, make_filter, run_latent
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_native_loaded():
+    from kvae import _native
+    lib = _native.hip_lib()
+    assert "gfx950" in lib.build_info
+    with open("/proc/self/maps") as f:
+        assert "libkvae_lgssm.so" in f.read()
+    assert _native._test_backend is None
+
+
+@pytest.mark.parametrize("name,kind", LATENT_CASES)
+def test_latent_gpu(name, kind):
+    """smooth + elbo + gradients vs the reference's own outputs (ELBO / smoothed means within 1e-4 rel)."""
+    g = load(name)
+    kf = make_filter(g, kind, DEV)
+    a, outs, elbo = run_latent(kf, g, DEV)
+    check_latent(kf, g, a, outs, elbo, name, tol_scale=2.0)
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_rocket_gpu(batch):
+    from kvae import noise
+    from kvae.kalman.kalman_filter import KalmanFilter
+    from kvae.kalman.switch_dyn_param import SwitchingDynamicsParameter
+    g = load(f"rocket_B{batch}")
+    dyn = SwitchingDynamicsParameter(g["A"], g["B"], g["C"])
+    kf = KalmanFilter(2.0, 4.0, g["mu0"], g["Sigma0"], dyn).to(DEV)
+    Y, U = g["Y"].to(DEV), g["U"].to(DEV)
+    with torch.no_grad(), noise.inject(eps_z=g["eps_z"]):
+        outs = kf.smooth(Y, U)
+        elbo = kf.elbo(outs[0], outs[1], Y, U, outs[6], outs[7], outs[8])
+    for k, v in zip(SMOOTH_KEYS, outs):
+        assert rel_err(v.cpu(), g[k]) < 5e-5, k
+    assert rel_err(elbo.cpu(), g["elbo"]) < 5e-5
+
+
+@pytest.mark.parametrize("name,kind,K", [("stability_lstm", "lstm", 3), ("stability_switching", "switching", 3),
+                                         ("stability_lstm_K7_T100", "lstm", 7),
+                                         ("stability_switching_K7_T100", "switching", 7)])
+def test_stability_recipe_gpu(name, kind, K):
+    """The reference's tests/test_imputation_stability.py recipe through the drop-in KVAE.impute."""
+    from kvae import noise
+    from kvae.model.model import KVAE
+    from kvae.utils.config import KVAEConfig
+    g = load(name)
+    T = int(g["T"])
+    model = KVAE(KVAEConfig(dynamics_model=kind, num_modes=K))
+    model.load_state_dict(stability_state_dict(kind, K), strict=True)
+    model.to(DEV).eval()
+    torch.manual_seed(123)
+    x = torch.randn(2, T, 1, 32, 32).to(DEV)
+    with noise.inject(eps_a=g["eps_a"], gumbel=g.get("gumbel")):
+        out = model.impute(x, g["mask"].to(DEV))
+    sl = slice(None) if g["x_recon"].shape[1] == T else slice(None, None, 10)
+    for k in ("x_recon", "x_imputed", "x_filtered"):
+        assert (out[k].cpu()[:, sl] - g[k]).abs().max() < 2e-6, k
+    for k in ("a_imputed", "a_filtered"):
+        assert (out[k].cpu() - g[k]).abs().max() < 1e-6, k
+
+
+@pytest.mark.parametrize("name,kind", [("trainstep_lstm_K3", "lstm"), ("trainstep_switch_K3", "switching")])
+def test_train_step_gpu(name, kind):
+    """One full step (forward, loss, backward, clip, Adam) vs the reference's recorded step."""
+    from kvae import noise
+    from kvae.model.model import KVAE
+    from kvae.utils.config import KVAEConfig
+    g = load(name)
+    model = KVAE(KVAEConfig(dynamics_model=kind, num_modes=3))
+    model.load_state_dict(sub(g, "sd."), strict=True)
+    model.to(DEV).train()
+    model.beta = float(g["beta"])
+    x = g["frames"].float().to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["lr"]))
+    with noise.inject(eps_a=g["eps_a"], eps_z=g["eps_z"], gumbel=g.get("gumbel")):
+        out = model(x, mask=torch.ones(x.shape[:2], device=DEV))
+        losses = model.compute_loss(x, out, mask=torch.ones(x.shape[:2], device=DEV))
+    losses["loss"].backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), float(g["clip"]))
+    opt.step()
+    assert rel_err(losses["loss"].detach().cpu(), g["loss"]) < 1e-4
+    assert rel_err(losses["elbo_kf"].detach().cpu(), g["elbo_kf"]) < 1e-4
+    assert rel_err(out["mus_smooth"].detach().cpu(), g["mus_smooth"]) < 1e-4
+    assert rel_err(gn.cpu(), g["grad_norm"]) < 1e-3
+    for k, p in model.named_parameters():
+        ref = float(g["gradnorm." + k])
+        assert abs(float(p.grad.norm()) - ref) <= 2e-3 * ref + 1e-6, k
+        if "grad." + k in g and ref > 1e-6:
+            assert rel_err(p.grad.cpu(), g["grad." + k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("B,T,n,m,p,K", [(256, 50, 4, 4, 2, 3), (7, 33, 4, 4, 2, 3), (5, 17, 3, 2, 1, 2),
+                                         (3, 9, 8, 5, 3, 4), (64, 200, 16, 16, 2, 3), (1, 1, 4, 4, 2, 3),
+                                         (2, 2, 16, 16, 2, 1)])
+def test_vs_oracle_random(B, T, n, m, p, K):
+    parity_cases.vs_oracle_random(DEV, B, T, n, m, p, K)
+
+
+def test_linearity_full_size():
+    parity_cases.linearity(DEV, 256, 50)
+
+
+def test_safe_cholesky_levels():
+    parity_cases.safe_cholesky_levels(DEV)
+
+
+def test_c_abi_direct_and_errors():
+    """Call the C ABI with raw device pointers (what a non-Python host would do) and check the error codes."""
+    from kvae import _native as N
+    lib = N.hip_lib()
+    B, T, n, m, p = 3, 5, 4, 4, 2
+    A, Bm, Cm, alpha, Y, U, mask, eps = _random_problem(B, T, n, m, p, 1, 3, DEV)
+    R, Q = 0.03 * torch.eye(p, device=DEV), 0.02 * torch.eye(n, device=DEV)
+    mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)
+    prob = N.Problem()
+    prob.B, prob.T, prob.n, prob.m, prob.p = B, T, n, m, p
+    prob.A, prob.Bm = N.Stack(A.data_ptr(), 0, 0), N.Stack(Bm.data_ptr(), 0, 0)
+    prob.C, prob.Q = N.Stack(Cm.data_ptr(), 0, 0), N.Stack(Q.data_ptr(), 0, 0)
+    prob.R, prob.mu0, prob.Sigma0, prob.Y, prob.U = R.data_ptr(), mu0.data_ptr(), S0.data_ptr(), Y.data_ptr(), U.data_ptr()
+    outs = [torch.empty(B, T, n, device=DEV) if i % 2 == 0 else torch.empty(B, T, n, n, device=DEV) for i in range(6)]
+    st = N.States(*[o.data_ptr() for o in outs])
+    assert lib.dll.kvae_lgssm_smooth_fwd(C.byref(prob), C.byref(st), None) == 0
+    torch.cuda.synchronize()
+    from oracle import c_oracle
+    c = lambda t: t.cpu()
+    ref = c_oracle.smooth(c(Y), c(U), None, c(A[0]), c(Bm[0]), c(Cm[0]), c(Q), c(R), c(mu0), c(S0))
+    assert rel_err(outs[4].cpu(), ref["mus_smooth"]) < 1e-4
+    prob.n = 17
+    assert lib.dll.kvae_lgssm_smooth_fwd(C.byref(prob), C.byref(st), None) == 1      # KVAE_ERR_DIMS
+    prob.n = n
+    prob.Y = None
+    assert lib.dll.kvae_lgssm_smooth_fwd(C.byref(prob), C.byref(st), None) == 2      # KVAE_ERR_NULL
+    assert lib.dll.kvae_mix_fwd(None, None, None, 1, 1, 1, None) == 2
+    assert lib.dll.kvae_mix_fwd(N.ptr(alpha), N.ptr(A), N.ptr(outs[1]), 1, 17, 1, None) == 4   # KVAE_ERR_ARG

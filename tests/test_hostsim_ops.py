@@ -109,3 +109,20 @@ def test_no_cpu_fallback():
             _native.lib_for(torch.zeros(1))
     finally:
         _native._set_test_backend(saved)
+
+
+@pytest.mark.parametrize("B,T,n,m,p,K", [(7, 33, 4, 4, 2, 3), (5, 17, 3, 2, 1, 2), (3, 9, 8, 5, 3, 4), (2, 12, 16, 16, 2, 3),
+                                         (1, 1, 4, 4, 2, 3), (2, 2, 16, 16, 2, 1)])
+def test_vs_oracle_random_hostsim(B, T, n, m, p, K):
+    import parity_cases
+    parity_cases.vs_oracle_random("cpu", B, T, n, m, p, K)
+
+
+def test_linearity_hostsim():
+    import parity_cases
+    parity_cases.linearity("cpu", 16, 20)
+
+
+def test_safe_cholesky_levels_hostsim():
+    import parity_cases
+    parity_cases.safe_cholesky_levels("cpu")
