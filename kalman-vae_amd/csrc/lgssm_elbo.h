@@ -194,8 +194,8 @@ KV_DEV void elbo_body(const D d, const kvae_lgssm_problem &P, const float *mus, 
   }
   KV_SYNC();
   // ---- quadratic forms (lane 0, serial) --------------------------------------------------------
-  float mk = 1.0f;
-  if (P.mask) mk = P.mask[q];
+  const float mv = *mask_addr(P, b, t);   // unconditional load from an always-valid address (see mask_addr)
+  const float mk = P.mask ? mv : 1.0f;
   if (has_prev) gauss_solve(L.LQ, n, L.dt, L.vt, &L.red[0]);
   if (has_next && grads) gauss_solve(L.LQn, n, L.dn, L.vn, &L.red[1]);
   gauss_solve(L.LR, p, L.em, L.qe, &L.red[2]);

@@ -35,6 +35,16 @@ struct StepOperands {  // register prefetch of step t+1 while step t computes (s
 KV_DEV const float *stack_at(const kvae_stack &s, int b, int t) { return s.ptr + (int64_t)b * s.sb + (int64_t)t * s.st; }
 KV_DEV float *gstack_at(const kvae_gstack &s, int b, int t) { return s.ptr + (int64_t)b * s.sb + (int64_t)t * s.st; }
 
+// Address of mask[b,t], or of a harmless valid float (R[0]) when every frame is observed (mask == NULL).
+// The single-element mask load is wave-uniform, so hipcc turns it into a SCALAR load; scalar loads
+// ignore EXEC and hipcc may drop the skip-branch around a short predicated block (observed on
+// ROCm 7.2: `if (mask) v = mask[i]` under `lane == 0` faulted on address nil).  Hence: always load
+// from a valid address, select afterwards.
+KV_DEV const float *mask_addr(const kvae_lgssm_problem &P, int b, int t) {
+  const int tc = t < P.T ? t : P.T - 1;  // a dropped skip-branch must not read past the last step either
+  return P.mask ? P.mask + (int64_t)b * P.T + tc : P.R;
+}
+
 template <class D>
 KV_DEV void operands_issue(const D d, const kvae_lgssm_problem &P, int b, int t, StepOperands<D> &pf) {
   const int n = d.n(), m = d.m(), p = d.p();
@@ -44,7 +54,7 @@ KV_DEV void operands_issue(const D d, const kvae_lgssm_problem &P, int b, int t,
   pf.q.issue(stack_at(P.Q, b, t), n * n);
   pf.y.issue(P.Y + ((int64_t)b * P.T + t) * p, p);
   pf.u.issue(P.U + ((int64_t)b * P.T + t) * m, m);
-  if (P.mask) pf.mk.issue(P.mask + (int64_t)b * P.T + t, 1);
+  pf.mk.issue(mask_addr(P, b, t), 1);
 }
 
 template <class D, class LDS>
@@ -56,7 +66,7 @@ KV_DEV void operands_commit(const D d, const kvae_lgssm_problem &P, const StepOp
   pf.q.commit(L.Q, n * n);
   pf.y.commit(L.y, p);
   pf.u.commit(L.u, m);
-  if (P.mask) pf.mk.commit(L.mk, 1);
+  KV_LANE0 { L.mk[0] = P.mask ? pf.mk.v[0] : 1.0f; }
 }
 
 template <class D, class LDS>
@@ -68,7 +78,8 @@ KV_DEV void operands_load(const D d, const kvae_lgssm_problem &P, int b, int t, 
   copy_in(L.Q, stack_at(P.Q, b, t), n * n);
   copy_in(L.y, P.Y + ((int64_t)b * P.T + t) * p, p);
   copy_in(L.u, P.U + ((int64_t)b * P.T + t) * m, m);
-  if (P.mask) copy_in(L.mk, P.mask + (int64_t)b * P.T + t, 1);
+  const float mv = *mask_addr(P, b, t);
+  KV_LANE0 { L.mk[0] = P.mask ? mv : 1.0f; }
 }
 
 // Recompute-able part of one filter step, shared by the forward and the backward sweep:
