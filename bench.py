@@ -20,10 +20,13 @@ for p in (str(ROOT), str(ROOT / "kalman-vae_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("DISABLE_ADDMM_CUDA_LT", "1")        # see kvae/train/train.py: hipBLASLt is not capture-safe
+os.environ.setdefault("TORCH_BLAS_PREFER_HIPBLASLT", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+_T0 = time.perf_counter()
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
 
 
@@ -50,11 +53,28 @@ def build_model(args, dev):
     return cfg, model.to(dev).train()
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, sd, frames, budget_s=25.0):
     """The oracle's restatement of the reference training step on the host cores (kind 'port')."""
     from oracle import torch_oracle as O
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
+    log(f"cpu_baseline: {threads} threads")
     B, T = frames.shape[:2]
     x = frames.float()
     tr = O.OracleTrainer(sd, args.dynamics, lr=7e-3, clip=10.0, beta=1.0)
@@ -70,10 +90,12 @@ def cpu_baseline(args, sd, frames, budget_s=25.0):
         tr.step(x, eps_a=eps_a, eps_z=eps_z, gumbel=gum)
         return time.perf_counter() - t0
 
-    one()  # warm-up (thread pools, oneDNN primitives)
+    w = one()  # warm-up (thread pools, oneDNN primitives)
+    log(f"cpu_baseline: warm-up step {w:.2f}s")
     times = [one()]
     while sum(times) < budget_s and len(times) < 4:
         times.append(one())
+    log(f"cpu_baseline: steps {[round(t, 2) for t in times]}")
     med = sorted(times)[len(times) // 2]
     return {"value": round(B / med, 2), "unit": "sequences/s", "cores": threads, "kind": "port",
             "sample": f"{len(times)} timed steps (after 1 warm-up) of the same workload, B={B} T={T}, "
@@ -101,6 +123,7 @@ def main():
     if dev.type != "cuda":
         raise SystemExit("bench.py needs a HIP device (the LGSSM path has no CPU fallback)")
     _native.hip_lib()
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building model")
     cfg, model = build_model(args, dev)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     B, T = args.batch, args.seq_len
@@ -124,6 +147,7 @@ def main():
             out = trainer.step(x)
     if args.no_graph:
         capture = "eager"
+    log(f"warm-up done ({capture}); timing {args.steps} steps")
 
     if world > 1:
         dist.barrier()
@@ -143,6 +167,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
+    log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} seq/s")
     # ---- roofline of the LGSSM kernel chain: HIP events around each C-ABI call, eager launches ----
     roofline, chain = None, {}
     if rank == 0:

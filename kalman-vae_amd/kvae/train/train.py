@@ -15,6 +15,12 @@ normalised by the local frame count, kalman_filter.py:392 / losses.py:82).
 """
 import os
 
+# hipBLASLt aborts the process when one of its calls lands inside hipGraph capture ("operation not
+# permitted when stream is capturing", hipblaslt.cpp:171 on ROCm 7.2): route the few small GEMMs of the
+# model (fc layers, LSTM head) through rocBLAS instead.  Must be set before the first addmm runs.
+os.environ.setdefault("DISABLE_ADDMM_CUDA_LT", "1")
+os.environ.setdefault("TORCH_BLAS_PREFER_HIPBLASLT", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -79,6 +85,10 @@ class Trainer:
         return self.out
 
     def _capture(self, x):
+        try:
+            torch.backends.cuda.preferred_blas_library("cublas")   # == rocBLAS on ROCm (see module header)
+        except Exception:
+            pass
         self.static_x = x.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
