@@ -135,6 +135,22 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
                  float *partials, int64_t rows, int32_t K, int32_t E, int32_t accumulate_alpha, void *stream);
 int64_t kvae_mix_bwd_partials(int64_t rows);
 
+/* ---- alpha-network recurrence ("lstm" dynamics) -------------------------------------------- */
+
+/* Single-layer LSTM over a whole batch of sequences from a zero state, torch gate order (i,f,g,o):
+ * replaces the T single-step nn.LSTM calls of DynamicsParameter.compute_step (dyn_param.py:50-52)
+ * when every frame is observed (its input at step t is then a_{t-1}, kalman_filter.py:142,183-185).
+ * x [B,T,I]; w_ih [4H,I]; w_hh [4H,H]; b_ih, b_hh [4H]; outputs h_seq [B,T,H], gates [B,T,4H]
+ * (post-activation, kept for the backward), c_seq [B,T,H].  Limits: H <= 52, I <= 16. */
+int kvae_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                  float *h_seq, float *gates, float *c_seq, int32_t B, int32_t T, int32_t I, int32_t H, void *stream);
+
+/* BPTT of kvae_lstm_fwd: from g_h [B,T,H] (gradient w.r.t. h_seq) produce d_pre [B,T,4H] (gradient
+ * w.r.t. the pre-activation gates) and dx [B,T,I].  The parameter gradients follow as plain GEMMs:
+ * dW_hh = d_pre^T h_{t-1}, dW_ih = d_pre^T x, db_ih = db_hh = sum d_pre. */
+int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, const float *w_ih, const float *w_hh,
+                  float *d_pre, float *dx, int32_t B, int32_t T, int32_t I, int32_t H, void *stream);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

@@ -215,3 +215,41 @@ const char *kvae_last_error(void) { return g_err; }
 const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "1"; }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// alpha-network LSTM (lstm.h): one wavefront per sequence, weights in LDS
+// ---------------------------------------------------------------------------------------------
+#include "lstm.h"
+
+__global__ __launch_bounds__(64) void k_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const float *b_ih,
+                                                 const float *b_hh, float *h_seq, float *gates, float *c_seq, int T, int I,
+                                                 int H) {
+  __shared__ LstmLds L;
+  lstm_fwd_body(x, w_ih, w_hh, b_ih, b_hh, h_seq, gates, c_seq, blockIdx.x, T, I, H, L);
+}
+
+__global__ __launch_bounds__(64) void k_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, const float *w_ih,
+                                                 const float *w_hh, float *d_pre, float *dx, int T, int I, int H) {
+  __shared__ LstmLds L;
+  lstm_bwd_body(g_h, gates, c_seq, w_ih, w_hh, d_pre, dx, blockIdx.x, T, I, H, L);
+}
+
+extern "C" {
+
+int kvae_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, float *h_seq,
+                  float *gates, float *c_seq, int32_t B, int32_t T, int32_t I, int32_t H, void *stream) {
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !h_seq || !gates || !c_seq) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || I < 1 || I > KVAE_LSTM_MAX_I || H < 1 || H > KVAE_LSTM_MAX_H) return KVAE_ERR_DIMS;
+  k_lstm_fwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(x, w_ih, w_hh, b_ih, b_hh, h_seq, gates, c_seq, T, I, H);
+  return launch_status("k_lstm_fwd");
+}
+
+int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, const float *w_ih, const float *w_hh,
+                  float *d_pre, float *dx, int32_t B, int32_t T, int32_t I, int32_t H, void *stream) {
+  if (!g_h || !gates || !c_seq || !w_ih || !w_hh || !d_pre || !dx) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || I < 1 || I > KVAE_LSTM_MAX_I || H < 1 || H > KVAE_LSTM_MAX_H) return KVAE_ERR_DIMS;
+  k_lstm_bwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(g_h, gates, c_seq, w_ih, w_hh, d_pre, dx, T, I, H);
+  return launch_status("k_lstm_bwd");
+}
+
+}  // extern "C"

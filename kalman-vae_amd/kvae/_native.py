@@ -16,6 +16,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
+LSTM_MAX_H, LSTM_MAX_I = 52, 16
 ABI_VERSION = 1
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
@@ -45,7 +46,8 @@ class InputGrads(C.Structure):  # kvae_lgssm_input_grads
 
 
 SYMBOLS = ("kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
-           "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_abi_version",
+           "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_lstm_fwd",
+           "kvae_lstm_bwd", "kvae_abi_version",
            "kvae_last_error", "kvae_build_info")
 
 
@@ -73,6 +75,10 @@ class LgssmLib:
         d.kvae_mix_bwd.restype = C.c_int
         d.kvae_mix_bwd_partials.argtypes = [C.c_int64]
         d.kvae_mix_bwd_partials.restype = C.c_int64
+        d.kvae_lstm_fwd.argtypes = [vp] * 8 + [C.c_int32] * 4 + [vp]
+        d.kvae_lstm_fwd.restype = C.c_int
+        d.kvae_lstm_bwd.argtypes = [vp] * 7 + [C.c_int32] * 4 + [vp]
+        d.kvae_lstm_bwd.restype = C.c_int
         d.kvae_abi_version.restype = C.c_int
         d.kvae_last_error.restype = C.c_char_p
         d.kvae_build_info.restype = C.c_char_p

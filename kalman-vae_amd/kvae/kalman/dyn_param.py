@@ -8,7 +8,8 @@ The recurrent net itself runs on PyTorch-ROCm (MIOpen RNN); the mixing A_t = sum
 import torch
 import torch.nn as nn
 
-from .lgssm_ops import Slots, mix_dynamics
+from .. import _native
+from .lgssm_ops import LstmSequence, Slots, mix_dynamics
 
 
 class DynamicsParameter(nn.Module):
@@ -42,7 +43,13 @@ class DynamicsParameter(nn.Module):
         if self.K == 1:
             return torch.ones(Bsz, T, 1, device=a_seq.device, dtype=a_seq.dtype)
         shifted = torch.cat([a_seq.new_zeros(Bsz, 1, self.p), a_seq[:, :-1]], dim=1)
-        h, self.lstm_state = self.lstm(shifted, None)
+        if self.lstm.hidden_size <= _native.LSTM_MAX_H and self.p <= _native.LSTM_MAX_I:
+            # hand-written HIP recurrence: one launch, weights in LDS, hipGraph-capturable
+            h = LstmSequence.apply(shifted, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0, self.lstm.bias_ih_l0,
+                                   self.lstm.bias_hh_l0)
+            self.lstm_state = None
+        else:  # hidden sizes beyond the LDS-resident kernel: PyTorch-ROCm (MIOpen) recurrence
+            h, self.lstm_state = self.lstm(shifted, None)
         return torch.softmax(self.head_w(h), dim=-1)
 
     def step_record(self, alpha):

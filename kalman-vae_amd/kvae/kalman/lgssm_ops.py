@@ -273,3 +273,44 @@ def mix_dynamics(alpha, mats):
         views.append(rec[..., o:o + e].unflatten(-1, (mt.shape[1], mt.shape[2])))
         o += e
     return rec, offs, views
+
+
+# ------------------------------------------------------------------------------------------------
+# alpha-network LSTM
+# ------------------------------------------------------------------------------------------------
+class LstmSequence(torch.autograd.Function):
+    """h_seq = LSTM(x) from a zero state (single layer, batch_first, torch gate order): the HIP replacement
+    for stepping nn.LSTM T times (reference dyn_param.py:50-52).  Backward: one BPTT launch + three GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
+        Bsz, T, I = x.shape
+        H = w_hh.shape[1]
+        mk = lambda *s: torch.empty(*s, device=x.device, dtype=torch.float32)
+        h, gates, c = mk(Bsz, T, H), mk(Bsz, T, 4 * H), mk(Bsz, T, H)
+        lib = N.lib_for(x)
+        lib.check(N.timed("lstm_fwd", x, lambda: lib.dll.kvae_lstm_fwd(
+            N.ptr(x), N.ptr(w_ih), N.ptr(w_hh), N.ptr(b_ih), N.ptr(b_hh), N.ptr(h), N.ptr(gates), N.ptr(c),
+            Bsz, T, I, H, N.stream_for(x))), "kvae_lstm_fwd")
+        ctx.save_for_backward(x, w_ih, w_hh, h, gates, c)
+        return h
+
+    @staticmethod
+    def backward(ctx, g_h):
+        x, w_ih, w_hh, h, gates, c = ctx.saved_tensors
+        g_h = _f32c(g_h)
+        Bsz, T, I = x.shape
+        H = w_hh.shape[1]
+        d_pre = torch.empty(Bsz, T, 4 * H, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        lib = N.lib_for(x)
+        lib.check(N.timed("lstm_bwd", x, lambda: lib.dll.kvae_lstm_bwd(
+            N.ptr(g_h), N.ptr(gates), N.ptr(c), N.ptr(w_ih), N.ptr(w_hh), N.ptr(d_pre), N.ptr(dx),
+            Bsz, T, I, H, N.stream_for(x))), "kvae_lstm_bwd")
+        d2 = d_pre.reshape(Bsz * T, 4 * H)
+        h_prev = torch.cat([h.new_zeros(Bsz, 1, H), h[:, :-1]], dim=1).reshape(Bsz * T, H)
+        g_whh = d2.t() @ h_prev
+        g_wih = d2.t() @ x.reshape(Bsz * T, I)
+        g_b = d2.sum(0)
+        return dx, g_wih, g_whh, g_b, g_b

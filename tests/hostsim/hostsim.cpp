@@ -144,3 +144,29 @@ int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
 const char *kvae_last_error(void) { return ""; }
 const char *kvae_build_info(void) { return "kvae_lgssm HOSTSIM (test-only host build of the kernel bodies)"; }
 }
+
+#include "../../kalman-vae_amd/csrc/lstm.h"
+extern "C" {
+int kvae_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, float *h_seq,
+                  float *gates, float *c_seq, int32_t B, int32_t T, int32_t I, int32_t H, void *) {
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !h_seq || !gates || !c_seq) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || I < 1 || I > KVAE_LSTM_MAX_I || H < 1 || H > KVAE_LSTM_MAX_H) return KVAE_ERR_DIMS;
+  auto L = std::make_unique<LstmLds>();
+  for (int b = 0; b < B; ++b) {
+    memset(L.get(), 0xFF, sizeof(*L));
+    lstm_fwd_body(x, w_ih, w_hh, b_ih, b_hh, h_seq, gates, c_seq, b, T, I, H, *L);
+  }
+  return KVAE_OK;
+}
+int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, const float *w_ih, const float *w_hh,
+                  float *d_pre, float *dx, int32_t B, int32_t T, int32_t I, int32_t H, void *) {
+  if (!g_h || !gates || !c_seq || !w_ih || !w_hh || !d_pre || !dx) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || I < 1 || I > KVAE_LSTM_MAX_I || H < 1 || H > KVAE_LSTM_MAX_H) return KVAE_ERR_DIMS;
+  auto L = std::make_unique<LstmLds>();
+  for (int b = 0; b < B; ++b) {
+    memset(L.get(), 0xFF, sizeof(*L));
+    lstm_bwd_body(g_h, gates, c_seq, w_ih, w_hh, d_pre, dx, b, T, I, H, *L);
+  }
+  return KVAE_OK;
+}
+}

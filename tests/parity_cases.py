@@ -107,3 +107,23 @@ def safe_cholesky_levels(DEV):
         assert levels[1] == want, levels
         for i in range(4):
             assert abs(float(terms[i]) - rterms[i]) <= 3e-4 * abs(rterms[i]) + 1e-3, (i, float(terms[i]), rterms[i])
+
+
+def lstm_vs_torch(DEV, B, T, I, H):
+    """kvae_lstm_fwd/bwd vs torch.nn.LSTM on the CPU (values and all gradients)."""
+    from kvae.kalman.lgssm_ops import LstmSequence
+    torch.manual_seed(B * 100 + T)
+    ref = torch.nn.LSTM(I, H, batch_first=True)
+    x = torch.randn(B, T, I)
+    w = torch.randn(B, T, H)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr)[0] * w).sum().backward()
+    params = [p.detach().clone().to(DEV).requires_grad_(True) for p in (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0,
+                                                                        ref.bias_hh_l0)]
+    xd = x.clone().to(DEV).requires_grad_(True)
+    h = LstmSequence.apply(xd, *params)
+    (h * w.to(DEV)).sum().backward()
+    assert rel_err(h.detach().cpu(), ref(x)[0].detach()) < 2e-5
+    assert rel_err(xd.grad.cpu(), xr.grad) < 1e-4
+    for got, want in zip(params, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)):
+        assert rel_err(got.grad.cpu(), want.grad) < 1e-4

@@ -148,3 +148,8 @@ def test_c_abi_direct_and_errors():
     assert lib.dll.kvae_lgssm_smooth_fwd(C.byref(prob), C.byref(st), None) == 2      # KVAE_ERR_NULL
     assert lib.dll.kvae_mix_fwd(None, None, None, 1, 1, 1, None) == 2
     assert lib.dll.kvae_mix_fwd(N.ptr(alpha), N.ptr(A), N.ptr(outs[1]), 1, 17, 1, None) == 4   # KVAE_ERR_ARG
+
+
+@pytest.mark.parametrize("B,T,I,H", [(256, 50, 2, 50), (3, 7, 2, 50), (2, 5, 5, 13)])
+def test_lstm_gpu(B, T, I, H):
+    parity_cases.lstm_vs_torch(DEV, B, T, I, H)

@@ -126,3 +126,9 @@ def test_linearity_hostsim():
 def test_safe_cholesky_levels_hostsim():
     import parity_cases
     parity_cases.safe_cholesky_levels("cpu")
+
+
+@pytest.mark.parametrize("B,T,I,H", [(3, 7, 2, 50), (2, 5, 5, 13), (1, 1, 2, 50)])
+def test_lstm_hostsim(B, T, I, H):
+    import parity_cases
+    parity_cases.lstm_vs_torch("cpu", B, T, I, H)
