@@ -220,6 +220,7 @@ const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one 
 // alpha-network LSTM (lstm.h): one wavefront per sequence, weights in LDS
 // ---------------------------------------------------------------------------------------------
 #include "lstm.h"
+#include "lstm_fast.h"
 
 __global__ __launch_bounds__(64) void k_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const float *b_ih,
                                                  const float *b_hh, float *h_seq, float *gates, float *c_seq, int T, int I,
@@ -240,7 +241,10 @@ int kvae_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const fl
                   float *gates, float *c_seq, int32_t B, int32_t T, int32_t I, int32_t H, void *stream) {
   if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !h_seq || !gates || !c_seq) return KVAE_ERR_NULL;
   if (B < 1 || T < 1 || I < 1 || I > KVAE_LSTM_MAX_I || H < 1 || H > KVAE_LSTM_MAX_H) return KVAE_ERR_DIMS;
-  k_lstm_fwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(x, w_ih, w_hh, b_ih, b_hh, h_seq, gates, c_seq, T, I, H);
+  if (H == 50 && I == 2)  // KVAEConfig defaults (dynamics_hidden_dim = 50, a_dim = 2): register-resident weights
+    k_lstm_fwd_fast<50, 2><<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(x, w_ih, w_hh, b_ih, b_hh, h_seq, gates, c_seq, T);
+  else
+    k_lstm_fwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(x, w_ih, w_hh, b_ih, b_hh, h_seq, gates, c_seq, T, I, H);
   return launch_status("k_lstm_fwd");
 }
 
@@ -248,7 +252,10 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
                   float *d_pre, float *dx, int32_t B, int32_t T, int32_t I, int32_t H, void *stream) {
   if (!g_h || !gates || !c_seq || !w_ih || !w_hh || !d_pre || !dx) return KVAE_ERR_NULL;
   if (B < 1 || T < 1 || I < 1 || I > KVAE_LSTM_MAX_I || H < 1 || H > KVAE_LSTM_MAX_H) return KVAE_ERR_DIMS;
-  k_lstm_bwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(g_h, gates, c_seq, w_ih, w_hh, d_pre, dx, T, I, H);
+  if (H == 50 && I == 2)
+    k_lstm_bwd_fast<50, 2><<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>(g_h, gates, c_seq, w_ih, w_hh, d_pre, dx, T);
+  else
+    k_lstm_bwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(g_h, gates, c_seq, w_ih, w_hh, d_pre, dx, T, I, H);
   return launch_status("k_lstm_bwd");
 }
 
