@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 1
+#define KVAE_ABI_VERSION 2
 
 typedef enum {
   KVAE_OK = 0,
@@ -63,7 +63,11 @@ typedef struct {
   float *Sigmas_pred;   /* [B,T,n,n] */
   float *mus_smooth;    /* [B,T,n]   (NULL for filter-only calls) */
   float *Sigmas_smooth; /* [B,T,n,n] */
+  float *aux;           /* optional [B,T,KVAE_AUX(n,p)]: gains saved by the forward for the backward
+                           (K unmasked [n,p] | S [p,p] | J [n,n]); NULL = recompute them. Only the
+                           n=4,p=2 fast path reads/writes it. */
 } kvae_lgssm_states;
+#define KVAE_AUX(n, p) ((n) * (p) + (p) * (p) + (n) * (n))
 
 /* Writable counterpart of kvae_stack: element (b,t) of a gradient stack starts at
  * ptr + b*sb + t*st.  Lets gA/gB/gC/gQ land directly in the slots of one packed [B,T,E] record. */

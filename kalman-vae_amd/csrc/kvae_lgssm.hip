@@ -14,6 +14,7 @@
 #include "lgssm_bwd.h"
 #include "lgssm_elbo.h"
 #include "lgssm_fwd.h"
+#include "lgssm_n4.h"
 #include "mix.h"
 
 using namespace kvae;
@@ -46,6 +47,33 @@ __global__ __launch_bounds__(64) void k_smooth_bwd(kvae_lgssm_problem P, kvae_lg
     filter_bwd_seed(d, P, U, G, ws, b);
   KV_SYNC();
   filter_bwd_sweep(d, P, S, G, ws, b, L);
+}
+
+// n = 4, p = 2 fused-phase kernels (lgssm_n4.h)
+template <class D>
+__global__ __launch_bounds__(64) void k_smooth_fwd_n4(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
+  __shared__ N4Lds<D::MMAX> L;
+  const D d(P.n, P.m, P.p);
+  const int b = blockIdx.x;
+  if (do_filter) {
+    filter_sweep_n4(d, P, S, b, L);
+    KV_SYNC();
+  }
+  if (do_rts) rts_sweep_n4(d, P, S, b, L);
+}
+
+template <class D>
+__global__ __launch_bounds__(64) void k_smooth_bwd_n4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
+                                                      kvae_lgssm_input_grads G, float *ws, int with_rts) {
+  __shared__ N4BwdLds<D::MMAX> L;
+  const D d(P.n, P.m, P.p);
+  const int b = blockIdx.x;
+  if (with_rts)
+    rts_bwd_sweep_n4(d, P, S, U, G, ws, b, L);
+  else
+    filter_bwd_seed(d, P, U, G, ws, b);
+  KV_SYNC();
+  filter_bwd_sweep_n4(d, P, S, G, ws, b, L);
 }
 
 template <class D>
@@ -83,9 +111,14 @@ __global__ void k_mix_bwd_partial(const float *alpha, const float *g_out, float 
   if (e < E) mix_bwd_partial_elem(alpha, g_out, partials, blockIdx.x, e, rows, K, E);
 }
 
-__global__ __launch_bounds__(256) void k_mix_bwd_final(const float *partials, float *g_base, int64_t nblk, int KE) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < KE) mix_bwd_final_elem(partials, g_base, idx, nblk, KE);
+// one wavefront per output element: lanes stride over the slab partials, then a fixed-order butterfly
+// (deterministic: the same summation tree on every run)
+__global__ __launch_bounds__(64) void k_mix_bwd_final(const float *partials, float *g_base, int64_t nblk, int KE) {
+  const int idx = blockIdx.x;
+  float acc = 0.f;
+  for (int64_t blk = threadIdx.x; blk < nblk; blk += 64) acc += partials[blk * KE + idx];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) g_base[idx] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -131,6 +164,11 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
   if (!st || !st->mus_filt || !st->Sigmas_filt || !st->mus_pred || !st->Sigmas_pred) return KVAE_ERR_NULL;
   if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
+  if (prob->n == 4 && prob->m == 4 && prob->p == 2 && (st->aux || !do_filter)) {
+    // rts-only calls need no gains; filter calls use the fused-phase kernel when the caller provides aux
+    k_smooth_fwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts);
+    return launch_status("k_smooth_fwd_n4");
+  }
   KVAE_DISPATCH(*prob, k_smooth_fwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts));
   return launch_status("k_smooth_fwd");
 }
@@ -156,6 +194,10 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (with_rts && (!saved->mus_smooth || !saved->Sigmas_smooth)) return KVAE_ERR_NULL;
   if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
+  if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {
+    k_smooth_bwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws, with_rts);
+    return launch_status("k_smooth_bwd_n4");
+  }
   KVAE_DISPATCH(*prob, k_smooth_bwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws,
                                            with_rts));
   return launch_status("k_smooth_bwd");
@@ -206,13 +248,13 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
   const int tpb = E >= 256 ? 256 : ((E + 63) / 64) * 64;
   hipLaunchKernelGGL(k_mix_bwd_partial, dim3((unsigned)nblk, (unsigned)((E + tpb - 1) / tpb)), dim3(tpb), 0, s, alpha, g_out,
                      partials, rows, K, E);
-  hipLaunchKernelGGL(k_mix_bwd_final, dim3((unsigned)((K * E + 255) / 256)), dim3(256), 0, s, partials, g_base, nblk, K * E);
+  hipLaunchKernelGGL(k_mix_bwd_final, dim3((unsigned)(K * E)), dim3(64), 0, s, partials, g_base, nblk, K * E);
   return launch_status("k_mix_bwd");
 }
 
 int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
 const char *kvae_last_error(void) { return g_err; }
-const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "1"; }
+const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "2"; }
 
 }  // extern "C"
 

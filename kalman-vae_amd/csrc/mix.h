@@ -6,7 +6,7 @@
 
 #include "lgssm_vm.h"
 
-#define KVAE_MIX_ROWS_PER_BLOCK 64
+#define KVAE_MIX_ROWS_PER_BLOCK 16
 #define KVAE_MAX_K 16
 
 namespace kvae {
@@ -37,10 +37,14 @@ KV_DEV void mix_bwd_partial_elem(const float *alpha, const float *g_out, float *
   for (int k = 0; k < KVAE_MAX_K; ++k) acc[k] = 0.f;
   const int64_t r0 = blk * KVAE_MIX_ROWS_PER_BLOCK;
   const int64_t r1 = (r0 + KVAE_MIX_ROWS_PER_BLOCK < rows) ? r0 + KVAE_MIX_ROWS_PER_BLOCK : rows;
-  for (int64_t r = r0; r < r1; ++r) {
-    const float g = g_out[r * E + e];
+  float g[KVAE_MIX_ROWS_PER_BLOCK];  // issue every row's load before the first use (independent, latency overlapped)
+  KV_UNROLL
+  for (int i = 0; i < KVAE_MIX_ROWS_PER_BLOCK; ++i) g[i] = (r0 + i < r1) ? g_out[(r0 + i) * E + e] : 0.0f;
+  KV_UNROLL
+  for (int i = 0; i < KVAE_MIX_ROWS_PER_BLOCK; ++i) {
+    const int64_t r = (r0 + i < r1) ? r0 + i : r0;
     for (int k = 0; k < KVAE_MAX_K; ++k)
-      if (k < K) acc[k] = fmaf(alpha[r * K + k], g, acc[k]);
+      if (k < K) acc[k] = fmaf(alpha[r * K + k], g[i], acc[k]);
   }
   for (int k = 0; k < KVAE_MAX_K; ++k)
     if (k < K) partials[(blk * K + k) * E + e] = acc[k];

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -37,7 +37,7 @@ class Problem(C.Structure):  # kvae_lgssm_problem
 
 class States(C.Structure):  # kvae_lgssm_states
     _fields_ = [(k, C.c_void_p) for k in ("mus_filt", "Sigmas_filt", "mus_pred", "Sigmas_pred",
-                                          "mus_smooth", "Sigmas_smooth")]
+                                          "mus_smooth", "Sigmas_smooth", "aux")]
 
 
 class InputGrads(C.Structure):  # kvae_lgssm_input_grads

@@ -80,10 +80,10 @@ class _Call:
         self.stream = N.stream_for(self.Y)
 
 
-def _states(mf, Sf, mp, Sp, ms=None, Ss=None):
+def _states(mf, Sf, mp, Sp, ms=None, Ss=None, aux=None):
     st = N.States()
     for k, t in (("mus_filt", mf), ("Sigmas_filt", Sf), ("mus_pred", mp), ("Sigmas_pred", Sp),
-                 ("mus_smooth", ms), ("Sigmas_smooth", Ss)):
+                 ("mus_smooth", ms), ("Sigmas_smooth", Ss), ("aux", aux)):
         setattr(st, k, t.data_ptr() if t is not None else None)
     return st
 
@@ -138,19 +138,21 @@ class LgssmSmooth(torch.autograd.Function):
         mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         mf, Sf, mp, Sp = mk(Bsz, T, n), mk(Bsz, T, n, n), mk(Bsz, T, n), mk(Bsz, T, n, n)
         ms, Ss = (mk(Bsz, T, n), mk(Bsz, T, n, n)) if with_rts else (None, None)
-        st = _states(mf, Sf, mp, Sp, ms, Ss)
+        # gains (K | S | J) kept for the backward; consumed by the n=4,p=2 fused-phase kernels
+        aux = mk(Bsz, T, n * p + p * p + n * n) if any(ctx.needs_input_grad) else None
+        st = _states(mf, Sf, mp, Sp, ms, Ss, aux)
         fn = call.lib.dll.kvae_lgssm_smooth_fwd if with_rts else call.lib.dll.kvae_lgssm_filter_fwd
         call.lib.check(N.timed("smooth_fwd" if with_rts else "filter_fwd", call.Y,
                                lambda: fn(C.byref(call.prob), C.byref(st), call.stream)), "kvae_lgssm_smooth_fwd")
         ctx.slots, ctx.with_rts = slots, with_rts
-        ctx.save_for_backward(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss)
+        ctx.save_for_backward(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss, aux)
         if with_rts:
             return ms, Ss, mf, Sf, mp, Sp
         return mf, Sf, mp, Sp
 
     @staticmethod
     def backward(ctx, *gouts):
-        Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss = ctx.saved_tensors
+        Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss, aux = ctx.saved_tensors
         slots, with_rts = ctx.slots, ctx.with_rts
         call = _Call(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots)
         Bsz, T, n, m, p = call.dims
@@ -170,7 +172,7 @@ class LgssmSmooth(torch.autograd.Function):
             S0 = torch.empty(Bsz, n, n, device=Y.device, dtype=torch.float32)
             sink.g.g_Sigma0 = S0.data_ptr()
         ws = torch.empty(Bsz, T, 2 * (n + n * n), device=Y.device, dtype=torch.float32)
-        saved = _states(mf, Sf, mp, Sp, ms, Ss)
+        saved = _states(mf, Sf, mp, Sp, ms, Ss, aux)
         up = _states(g_mf, g_Sf, g_mp, g_Sp, g_ms, g_Ss)
         call.lib.check(N.timed("smooth_bwd", call.Y, lambda: call.lib.dll.kvae_lgssm_smooth_bwd(
             C.byref(call.prob), C.byref(saved), C.byref(up), C.byref(sink.g), N.ptr(ws), int(with_rts), call.stream)),

@@ -15,6 +15,7 @@
 #include "../../kalman-vae_amd/csrc/lgssm_bwd.h"
 #include "../../kalman-vae_amd/csrc/lgssm_elbo.h"
 #include "../../kalman-vae_amd/csrc/lgssm_fwd.h"
+#include "../../kalman-vae_amd/csrc/lgssm_n4.h"
 #include "../../kalman-vae_amd/csrc/mix.h"
 
 using namespace kvae;
@@ -51,6 +52,32 @@ static void run_fwd(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, int
     memset(L.get(), 0xFF, sizeof(*L));  // poison: NaNs expose reads of unwritten scratch
     if (do_filter) filter_sweep(d, P, S, b, *L);
     if (do_rts) rts_sweep(d, P, S, b, *L);
+  }
+}
+
+static void run_fwd_n4(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, int do_filter, int do_rts) {
+  using D = SDims<4, 4, 2>;
+  auto L = std::make_unique<N4Lds<4>>();
+  const D d(P.n, P.m, P.p);
+  for (int b = 0; b < P.B; ++b) {
+    memset(L.get(), 0xFF, sizeof(*L));
+    if (do_filter) filter_sweep_n4(d, P, S, b, *L);
+    if (do_rts) rts_sweep_n4(d, P, S, b, *L);
+  }
+}
+
+static void run_bwd_n4(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                       const kvae_lgssm_input_grads &G, float *ws, int with_rts) {
+  using D = SDims<4, 4, 2>;
+  auto L = std::make_unique<N4BwdLds<4>>();
+  const D d(P.n, P.m, P.p);
+  for (int b = 0; b < P.B; ++b) {
+    memset(L.get(), 0xFF, sizeof(*L));
+    if (with_rts)
+      rts_bwd_sweep_n4(d, P, S, U, G, ws, b, *L);
+    else
+      filter_bwd_seed(d, P, U, G, ws, b);
+    filter_bwd_sweep_n4(d, P, S, G, ws, b, *L);
   }
 }
 
@@ -94,6 +121,10 @@ static int fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int 
   if (rc) return rc;
   if (!st || !st->mus_filt || !st->Sigmas_filt || !st->mus_pred || !st->Sigmas_pred) return KVAE_ERR_NULL;
   if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
+  if (prob->n == 4 && prob->m == 4 && prob->p == 2 && (st->aux || !do_filter)) {
+    run_fwd_n4(*prob, *st, do_filter, do_rts);
+    return KVAE_OK;
+  }
   KVAE_DISPATCH(*prob, (run_fwd<D>(*prob, *st, do_filter, do_rts)));
   return KVAE_OK;
 }
@@ -107,6 +138,10 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (rc) return rc;
   if (!saved || !up || !out || !ws) return KVAE_ERR_NULL;
   if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
+  if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {
+    run_bwd_n4(*prob, *saved, *up, *out, ws, with_rts);
+    return KVAE_OK;
+  }
   KVAE_DISPATCH(*prob, (run_bwd<D>(*prob, *saved, *up, *out, ws, with_rts)));
   return KVAE_OK;
 }

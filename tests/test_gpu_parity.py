@@ -134,7 +134,7 @@ def test_c_abi_direct_and_errors():
     prob.C, prob.Q = N.Stack(Cm.data_ptr(), 0, 0), N.Stack(Q.data_ptr(), 0, 0)
     prob.R, prob.mu0, prob.Sigma0, prob.Y, prob.U = R.data_ptr(), mu0.data_ptr(), S0.data_ptr(), Y.data_ptr(), U.data_ptr()
     outs = [torch.empty(B, T, n, device=DEV) if i % 2 == 0 else torch.empty(B, T, n, n, device=DEV) for i in range(6)]
-    st = N.States(*[o.data_ptr() for o in outs])
+    st = N.States(*[o.data_ptr() for o in outs], None)
     assert lib.dll.kvae_lgssm_smooth_fwd(C.byref(prob), C.byref(st), None) == 0
     torch.cuda.synchronize()
     from oracle import c_oracle

@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""Per-kernel average of one rocprofv3 --pmc counter (CSV): prof dir -> 'kernel avg_value calls'."""
+"""Per-kernel averages of rocprofv3 --pmc counters (CSV). usage: pmc_summary.py <dir> [COUNTER ...]"""
 import collections, csv, glob, sys
-d, name = sys.argv[1], sys.argv[2]
+d, names = sys.argv[1], sys.argv[2:]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-acc = collections.defaultdict(lambda: [0, 0.0])
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(f)):
-    if r["Counter_Name"] != name:
+    if names and r["Counter_Name"] not in names:
         continue
-    k = r["Kernel_Name"].split("(")[0][:60]
-    acc[k][0] += 1
-    acc[k][1] += float(r["Counter_Value"])
-for k, (c, v) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-    if k.startswith(("void k_", "k_", "void kvae", "_ZN4kvae")):
-        print(f"{name} {v / c:14.1f} avg over {c:4d} calls  {k}")
+    k = r["Kernel_Name"].split("(")[0][:48]
+    if not any(t in k for t in ("k_smooth", "k_elbo", "k_mix", "k_lstm", "k_regime", "k_vae")):
+        continue
+    a = acc[k][r["Counter_Name"]]
+    a[0] += 1
+    a[1] += float(r["Counter_Value"])
+for k, cs in acc.items():
+    print(k)
+    for c, (n, v) in sorted(cs.items()):
+        print(f"    {c:24s} {v / n:16.1f}   (avg over {n} launches)")
