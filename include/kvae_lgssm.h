@@ -155,6 +155,20 @@ int kvae_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const fl
 int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, const float *w_ih, const float *w_hh,
                   float *d_pre, float *dx, int32_t B, int32_t T, int32_t I, int32_t H, void *stream);
 
+/* ---- fused conv epilogues of the frame VAE ------------------------------------------------- */
+
+/* out[N,C,H*r,W*r] = act(pixel_shuffle_r(in[N,C*r*r,H,W] + bias[C*r*r])), act = ReLU if relu != 0, r in {1,2,..}:
+ * replaces the separate bias-add / nn.PixelShuffle / nn.ReLU passes after each conv of the reference's
+ * Encoder / Decoder (kvae/vae/vae.py:20-31, 92-101). */
+int kvae_bias_shuffle_act_fwd(const float *in, const float *bias, float *out, int64_t N, int32_t C, int32_t H,
+                              int32_t W, int32_t r, int32_t relu, void *stream);
+/* g_in = pixel_unshuffle_r(g_out * [out > 0]).  If bias_partials != NULL ([kvae_bias_partial_rows(N), C*r*r] floats,
+ * zeroed by the call) it receives per-sample-chunk partial sums of g_in over (n,h,w): the bias gradient is their
+ * column sum. */
+int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in, float *bias_partials, int64_t N,
+                              int32_t C, int32_t H, int32_t W, int32_t r, int32_t relu, void *stream);
+int64_t kvae_bias_partial_rows(int64_t N);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

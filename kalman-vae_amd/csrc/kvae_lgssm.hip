@@ -302,3 +302,136 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// fused conv epilogues of the frame VAE (vae_epilogue.h)
+// ---------------------------------------------------------------------------------------------
+#include "vae_epilogue.h"
+
+// Forward, R = 1 or 2: each thread produces 4 consecutive outputs along W (one 16-byte store) from one 16-byte
+// (R = 1) or two 8-byte (R = 2: the two sub-pixel channels dx = 0,1 of this output row) loads; 32-bit index math.
+template <int R>
+__global__ __launch_bounds__(256) void k_vae_epilogue_fwd_v4(const float *__restrict__ in, const float *__restrict__ bias,
+                                                             float *__restrict__ out, int C, int H, int W, int64_t quads,
+                                                             int relu) {
+  const int OW = W * R, OH = H * R, QW = OW / 4;
+  for (int64_t qd = (int64_t)blockIdx.x * 256 + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * 256) {
+    const int qw = (int)(qd % QW);
+    const int64_t t1 = qd / QW;
+    const int oh = (int)(t1 % OH);
+    const int64_t t2 = t1 / OH;
+    const int c = (int)(t2 % C);
+    const int64_t n = t2 / C;
+    float4 v;
+    if (R == 1) {
+      const float b = bias[c];
+      const float4 x = *reinterpret_cast<const float4 *>(in + ((n * C + c) * H + oh) * W + 4 * qw);
+      v = make_float4(x.x + b, x.y + b, x.z + b, x.w + b);
+    } else {
+      const int ch0 = c * 4 + (oh & 1) * 2;
+      const int64_t base = ((n * (C * 4) + ch0) * H + (oh >> 1)) * W + 2 * qw;
+      const float2 a = *reinterpret_cast<const float2 *>(in + base);                    // dx = 0, w = 2qw, 2qw+1
+      const float2 d = *reinterpret_cast<const float2 *>(in + base + (int64_t)H * W);  // dx = 1
+      const float b0 = bias[ch0], b1 = bias[ch0 + 1];
+      v = make_float4(a.x + b0, d.x + b1, a.y + b0, d.y + b1);
+    }
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    *reinterpret_cast<float4 *>(out + qd * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_vae_epilogue_fwd(const float *in, const float *bias, float *out, EpiShape s,
+                                                          int64_t total, int relu) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256)
+    epi_fwd_elem(s, in, bias, out, o, relu);
+}
+
+// Backward with the bias gradient folded in: a block owns 256 consecutive output positions of the per-sample volume
+// [C, H*r, W*r] and walks a chunk of samples; per-thread sums go to per-channel LDS bins (ds_add_f32), one partial row
+// per (chunk, channel) leaves the block -> bias_partials[chunk, C*r*r] (summed by the caller; fixed order per bin is not
+// guaranteed inside a block: float LDS atomics, differences are at rounding level).
+__global__ __launch_bounds__(256) void k_vae_epilogue_bwd_bias(const float *__restrict__ g_out, const float *__restrict__ out,
+                                                               float *__restrict__ g_in, float *__restrict__ bias_partials,
+                                                               EpiShape s, int n_per_chunk, int relu) {
+  extern __shared__ float bins[];   // C*r*r floats
+  const int Cin = s.C * s.r * s.r;
+  const int OW = s.W * s.r, OH = s.H * s.r;
+  const int64_t vol = (int64_t)s.C * OH * OW;
+  for (int i = threadIdx.x; i < Cin; i += 256) bins[i] = 0.f;
+  __syncthreads();
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;   // position inside one sample's output volume
+  if (pos < vol) {
+    const int ow = (int)(pos % OW);
+    const int oh = (int)((pos / OW) % OH);
+    const int c = (int)(pos / ((int64_t)OW * OH));
+    const int ch = c * s.r * s.r + (oh % s.r) * s.r + (ow % s.r);
+    const int64_t in_off = ((int64_t)ch * s.H + oh / s.r) * s.W + ow / s.r;
+    const int64_t in_vol = (int64_t)Cin * s.H * s.W;
+    const int64_t n0 = (int64_t)blockIdx.y * n_per_chunk;
+    const int64_t n1 = n0 + n_per_chunk < s.N ? n0 + n_per_chunk : s.N;
+    float acc = 0.f;
+    for (int64_t n = n0; n < n1; ++n) {
+      float g = g_out[n * vol + pos];
+      if (relu && !(out[n * vol + pos] > 0.f)) g = 0.f;
+      g_in[n * in_vol + in_off] = g;
+      acc += g;
+    }
+    atomicAdd(&bins[ch], acc);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cin; i += 256) {
+    // only the channels this block touched are non-zero; every block writes its own disjoint partial row slice
+    if (bins[i] != 0.f) atomicAdd(&bias_partials[(int64_t)blockIdx.y * Cin + i], bins[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_vae_epilogue_bwd(const float *g_out, const float *out, float *g_in, EpiShape s,
+                                                          int64_t total, int relu) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256)
+    epi_bwd_elem(s, g_out, out, g_in, o, relu);
+}
+
+#define KVAE_EPI_SAMPLES_PER_CHUNK 32
+extern "C" int64_t kvae_bias_partial_rows(int64_t N);
+static unsigned epi_grid(int64_t total) {
+  const int64_t blocks = (total + 255) / 256;
+  return (unsigned)(blocks < 256 * 32 ? blocks : 256 * 32);   // <= 32 blocks per CU, grid-stride the rest
+}
+
+extern "C" {
+int kvae_bias_shuffle_act_fwd(const float *in, const float *bias, float *out, int64_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t r, int32_t relu, void *stream) {
+  if (!in || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1 || C < 1 || H < 1 || W < 1 || r < 1) return KVAE_ERR_ARG;
+  const EpiShape s{N, C, H, W, r};
+  const int64_t total = N * C * H * W * r * r;
+  const bool aligned = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (aligned && r == 1 && W % 4 == 0)
+    k_vae_epilogue_fwd_v4<1><<<dim3(epi_grid(total / 4)), dim3(256), 0, (hipStream_t)stream>>>(in, bias, out, C, H, W, total / 4, relu);
+  else if (aligned && r == 2 && W % 2 == 0)
+    k_vae_epilogue_fwd_v4<2><<<dim3(epi_grid(total / 4)), dim3(256), 0, (hipStream_t)stream>>>(in, bias, out, C, H, W, total / 4, relu);
+  else
+    k_vae_epilogue_fwd<<<dim3(epi_grid(total)), dim3(256), 0, (hipStream_t)stream>>>(in, bias, out, s, total, relu);
+  return launch_status("k_vae_epilogue_fwd");
+}
+int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in, float *bias_partials, int64_t N, int32_t C,
+                              int32_t H, int32_t W, int32_t r, int32_t relu, void *stream) {
+  if (!g_out || !g_in || (relu && !out)) return KVAE_ERR_NULL;
+  if (N < 1 || C < 1 || H < 1 || W < 1 || r < 1) return KVAE_ERR_ARG;
+  const EpiShape s{N, C, H, W, r};
+  const int64_t total = N * C * H * W * r * r;
+  hipStream_t st = (hipStream_t)stream;
+  if (bias_partials) {
+    const int Cin = C * r * r;
+    const int64_t chunks = kvae_bias_partial_rows(N);
+    if (hipMemsetAsync(bias_partials, 0, sizeof(float) * chunks * Cin, st) != hipSuccess) return launch_status("memset bias_partials");
+    const int64_t vol = (int64_t)C * H * W * r * r;
+    k_vae_epilogue_bwd_bias<<<dim3((unsigned)((vol + 255) / 256), (unsigned)chunks), dim3(256), sizeof(float) * Cin, st>>>(
+        g_out, out, g_in, bias_partials, s, KVAE_EPI_SAMPLES_PER_CHUNK, relu);
+    return launch_status("k_vae_epilogue_bwd_bias");
+  }
+  k_vae_epilogue_bwd<<<dim3(epi_grid(total)), dim3(256), 0, st>>>(g_out, out, g_in, s, total, relu);
+  return launch_status("k_vae_epilogue_bwd");
+}
+int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHUNK - 1) / KVAE_EPI_SAMPLES_PER_CHUNK; }
+}  // extern "C"

@@ -47,7 +47,7 @@ class InputGrads(C.Structure):  # kvae_lgssm_input_grads
 
 SYMBOLS = ("kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
            "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_lstm_fwd",
-           "kvae_lstm_bwd", "kvae_abi_version",
+           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_abi_version",
            "kvae_last_error", "kvae_build_info")
 
 
@@ -79,6 +79,12 @@ class LgssmLib:
         d.kvae_lstm_fwd.restype = C.c_int
         d.kvae_lstm_bwd.argtypes = [vp] * 7 + [C.c_int32] * 4 + [vp]
         d.kvae_lstm_bwd.restype = C.c_int
+        d.kvae_bias_shuffle_act_fwd.argtypes = [vp, vp, vp, C.c_int64] + [C.c_int32] * 5 + [vp]
+        d.kvae_bias_shuffle_act_fwd.restype = C.c_int
+        d.kvae_bias_shuffle_act_bwd.argtypes = [vp, vp, vp, vp, C.c_int64] + [C.c_int32] * 5 + [vp]
+        d.kvae_bias_shuffle_act_bwd.restype = C.c_int
+        d.kvae_bias_partial_rows.argtypes = [C.c_int64]
+        d.kvae_bias_partial_rows.restype = C.c_int64
         d.kvae_abi_version.restype = C.c_int
         d.kvae_last_error.restype = C.c_char_p
         d.kvae_build_info.restype = C.c_char_p
@@ -115,6 +121,11 @@ def _set_test_backend(lib):
     """TEST-ONLY: route ops on host tensors to the host simulator of the kernel bodies."""
     global _test_backend
     _test_backend = lib
+
+
+def fused_ok(t: torch.Tensor) -> bool:
+    """True when the HIP kernels can take this tensor (HIP device, or a test injected the host simulator)."""
+    return t.is_cuda or _test_backend is not None
 
 
 def lib_for(t: torch.Tensor):

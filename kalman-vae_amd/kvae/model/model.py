@@ -68,7 +68,9 @@ class KVAE(nn.Module):
         return torch.sigmoid(logits) if self.config.out_distr.lower() == "bernoulli" else logits
 
     # -- full pass ------------------------------------------------------------------------------
-    def forward(self, x, u=None, mask=None):
+    def forward(self, x, u=None, mask=None, with_recon=True):
+        """`with_recon=False` (addition over the reference) skips sigmoid(x_logits): the training loss only
+        needs the logits, so the step saves one full pass over the frame tensor."""
         a_samples, a_mu, a_var = self.encode_sequence(x)
         if u is None:
             u = torch.zeros(x.shape[0], x.shape[1], self.u_dim, device=x.device, dtype=x.dtype)
@@ -77,7 +79,7 @@ class KVAE(nn.Module):
          A_list, B_list, C_list) = self.kalman_filter.smooth(a_samples, u, mask=mask)
         x_logits = self.decode_sequence(a_samples)
         return {
-            "x_recon": self._to_pixels(x_logits), "x_logits": x_logits,
+            "x_recon": self._to_pixels(x_logits) if with_recon else None, "x_logits": x_logits,
             "a_samples": a_samples, "a_mu": a_mu, "a_var": a_var,
             "mus_smooth": mus_smooth, "Sigmas_smooth": Sigmas_smooth,
             "mus_filt": mus_filt, "Sigmas_filt": Sigmas_filt,
@@ -95,7 +97,7 @@ class KVAE(nn.Module):
         u = outputs.get("u")
         if u is None:
             u = torch.zeros(B, T, self.u_dim, device=x.device, dtype=x.dtype)
-        x_mu = outputs.get("x_logits", outputs["x_recon"])
+        x_mu = outputs["x_logits"] if outputs.get("x_logits") is not None else outputs["x_recon"]
         x_var = torch.tensor(self.config.noise_pixel_var, device=x.device, dtype=x_mu.dtype) \
             if self.config.out_distr.lower() != "bernoulli" else None
         vae_elbo, recon, reg = vae_loss(x, x_mu, x_var, a, a_mu, a_var,

@@ -49,7 +49,7 @@ class Trainer:
     def _forward_backward(self, x):
         self.flat_grad.zero_()
         self.model.kalman_filter.dyn_params.reset_state()
-        outputs = self.model(x, mask=None)          # all frames observed == mask of ones (train.py:41)
+        outputs = self.model(x, mask=None, with_recon=False)   # all frames observed == mask of ones (train.py:41)
         losses = self.model.compute_loss(x, outputs, kf_weight=self.kf_weight, vae_weight=self.vae_weight, mask=None,
                                          with_metrics=False)
         losses["loss"].backward()

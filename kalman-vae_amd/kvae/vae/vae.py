@@ -9,7 +9,9 @@ from typing import Tuple
 import torch
 import torch.nn as nn
 
+from kvae import _native
 from kvae.utils.config import KVAEConfig
+from kvae.vae.fused import conv_block
 
 
 def _conv_out(size, k, s, p):
@@ -34,7 +36,14 @@ class Encoder(nn.Module):
         self.fc_var = nn.Sequential(nn.Linear(self.flat_size, config.a_dim), nn.Sigmoid())
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        feat = self.conv_layers(x).flatten(1)
+        if _native.fused_ok(x) and x.dtype == torch.float32:
+            h = x   # conv on MIOpen, then ONE fused bias+ReLU pass per layer (csrc/vae_epilogue.h)
+            for layer in self.conv_layers:
+                if isinstance(layer, nn.Conv2d):
+                    h = conv_block(h, layer, r=1, relu=True)
+            feat = h.flatten(1)
+        else:
+            feat = self.conv_layers(x).flatten(1)
         return self.fc_mu(feat), self.config.noise_emission * self.fc_var(feat)
 
 
@@ -56,7 +65,14 @@ class Decoder(nn.Module):
 
     def forward(self, a: torch.Tensor) -> torch.Tensor:
         h = self.fc(a).unflatten(1, (self.init_channels, self.init_size, self.init_size))
-        return self.deconv_layers(h)
+        if not (_native.fused_ok(h) and h.dtype == torch.float32):
+            return self.deconv_layers(h)
+        layers = list(self.deconv_layers)   # conv -> PixelShuffle(2) [-> ReLU] triples, fused per conv
+        for i, layer in enumerate(layers):
+            if isinstance(layer, nn.Conv2d):
+                relu = i + 2 < len(layers) and isinstance(layers[i + 2], nn.ReLU)
+                h = conv_block(h, layer, r=2, relu=relu)
+        return h
 
 
 class VAE(nn.Module):

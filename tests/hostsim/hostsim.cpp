@@ -205,3 +205,32 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
   return KVAE_OK;
 }
 }
+
+#include "../../kalman-vae_amd/csrc/vae_epilogue.h"
+extern "C" {
+int kvae_bias_shuffle_act_fwd(const float *in, const float *bias, float *out, int64_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t r, int32_t relu, void *) {
+  if (!in || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1 || C < 1 || H < 1 || W < 1 || r < 1) return KVAE_ERR_ARG;
+  const EpiShape s{N, C, H, W, r};
+  for (int64_t o = 0; o < N * C * H * W * r * r; ++o) epi_fwd_elem(s, in, bias, out, o, relu);
+  return KVAE_OK;
+}
+int64_t kvae_bias_partial_rows(int64_t N) { return (N + 31) / 32; }
+int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in, float *bias_partials, int64_t N, int32_t C,
+                              int32_t H, int32_t W, int32_t r, int32_t relu, void *) {
+  if (!g_out || !g_in || (relu && !out)) return KVAE_ERR_NULL;
+  if (N < 1 || C < 1 || H < 1 || W < 1 || r < 1) return KVAE_ERR_ARG;
+  const EpiShape s{N, C, H, W, r};
+  const int64_t vol = (int64_t)C * H * W * r * r;
+  for (int64_t o = 0; o < N * vol; ++o) epi_bwd_elem(s, g_out, out, g_in, o, relu);
+  if (bias_partials) {
+    const int Cin = C * r * r;
+    memset(bias_partials, 0, sizeof(float) * kvae_bias_partial_rows(N) * Cin);
+    for (int64_t n = 0; n < N; ++n)
+      for (int ch = 0; ch < Cin; ++ch)
+        for (int k = 0; k < H * W; ++k) bias_partials[(n / 32) * Cin + ch] += g_in[(n * Cin + ch) * H * W + k];
+  }
+  return KVAE_OK;
+}
+}

@@ -127,3 +127,23 @@ def lstm_vs_torch(DEV, B, T, I, H):
     assert rel_err(xd.grad.cpu(), xr.grad) < 1e-4
     for got, want in zip(params, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)):
         assert rel_err(got.grad.cpu(), want.grad) < 1e-4
+
+
+def vae_epilogue_vs_torch(DEV, N, C, H, W, r, relu):
+    """kvae_bias_shuffle_act_fwd/bwd vs conv-bias + nn.PixelShuffle + nn.ReLU of torch (values and gradients)."""
+    import torch.nn.functional as F
+    from kvae.vae.fused import BiasShuffleAct
+    g = torch.Generator().manual_seed(N + C + H)
+    x = torch.randn(N, C * r * r, H, W, generator=g)
+    b = torch.randn(C * r * r, generator=g)
+    w = torch.randn(N, C, H * r, W * r, generator=g)
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.pixel_shuffle(xr + br.view(1, -1, 1, 1), r) if r > 1 else xr + br.view(1, -1, 1, 1)
+    ref = F.relu(ref) if relu else ref
+    (ref * w).sum().backward()
+    xd, bd = x.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)
+    out = BiasShuffleAct.apply(xd, bd, r, relu)
+    (out * w.to(DEV)).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+    assert rel_err(bd.grad.cpu(), br.grad) < 1e-5

@@ -153,3 +153,8 @@ def test_c_abi_direct_and_errors():
 @pytest.mark.parametrize("B,T,I,H", [(256, 50, 2, 50), (3, 7, 2, 50), (2, 5, 5, 13)])
 def test_lstm_gpu(B, T, I, H):
     parity_cases.lstm_vs_torch(DEV, B, T, I, H)
+
+
+@pytest.mark.parametrize("N,C,H,W,r,relu", [(64, 32, 8, 8, 2, True), (7, 1, 16, 16, 2, False), (33, 32, 16, 16, 1, True)])
+def test_vae_epilogue_gpu(N, C, H, W, r, relu):
+    parity_cases.vae_epilogue_vs_torch(DEV, N, C, H, W, r, relu)

@@ -132,3 +132,30 @@ def test_safe_cholesky_levels_hostsim():
 def test_lstm_hostsim(B, T, I, H):
     import parity_cases
     parity_cases.lstm_vs_torch("cpu", B, T, I, H)
+
+
+@pytest.mark.parametrize("N,C,H,W,r,relu", [(3, 8, 4, 4, 2, True), (2, 1, 16, 16, 2, False), (5, 6, 8, 8, 1, True), (2, 3, 5, 7, 3, True)])
+def test_vae_epilogue_hostsim(N, C, H, W, r, relu):
+    import parity_cases
+    parity_cases.vae_epilogue_vs_torch("cpu", N, C, H, W, r, relu)
+
+
+def test_vae_fused_matches_unfused_hostsim():
+    """Encoder/Decoder with the fused epilogues == the plain nn.Sequential path (same weights)."""
+    from kvae import _native
+    from kvae.utils.config import KVAEConfig
+    from kvae.vae.vae import Decoder, Encoder
+    torch.manual_seed(0)
+    cfg = KVAEConfig()
+    enc, dec = Encoder(cfg), Decoder(cfg)
+    x, a = torch.rand(6, 1, 32, 32), torch.randn(6, 2)
+    mu_f, var_f = enc(x)
+    out_f = dec(a)
+    saved = _native._test_backend
+    _native._set_test_backend(None)
+    try:
+        mu_p, var_p = enc(x)
+        out_p = dec(a)
+    finally:
+        _native._set_test_backend(saved)
+    assert rel_err(mu_f, mu_p) < 1e-6 and rel_err(var_f, var_p) < 1e-6 and rel_err(out_f, out_p) < 1e-6
