@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--z-dim", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the LGSSM chain on the main stream")
     args = ap.parse_args()
 
     from kvae import _native
@@ -136,7 +137,7 @@ def main():
     x = frames.float().to(dev)
 
     capture = "hipgraph"
-    trainer = Trainer(model, use_graph=not args.no_graph, world_size=world)
+    trainer = Trainer(model, use_graph=not args.no_graph, world_size=world, overlap_lgssm=not args.no_overlap)
     try:
         for _ in range(max(args.warmup, 1)):
             out = trainer.step(x)

@@ -155,6 +155,18 @@ int kvae_lstm_fwd(const float *x, const float *w_ih, const float *w_hh, const fl
 int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, const float *w_ih, const float *w_hh,
                   float *d_pre, float *dx, int32_t B, int32_t T, int32_t I, int32_t H, void *stream);
 
+/* ---- regime chain of the switching dynamics -------------------------------------------------- */
+
+/* Sequential Gumbel-softmax Markov chain over T steps (switch_dyn_param.py:52-79): logits [B,T,K,K] (slice t=0
+ * unused), init_logits [B,K], gumbel noise [B,T,K], prior transition P [K,K], temperature tau, hard != 0 for the
+ * straight-through one-hot of eval mode.  Outputs y_seq [B,T,K], log_q [B,T], log_p [B,T].  K <= 16. */
+int kvae_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, float *y_seq,
+                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, int32_t hard, void *stream);
+/* BPTT of kvae_regime_fwd: upstream g_y [B,T,K], g_log_q [B,T], g_log_p [B,T] -> g_logits [B,T,K,K], g_init [B,K]. */
+int kvae_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                    const float *y_seq, const float *g_y, const float *g_log_q, const float *g_log_p, float *g_logits,
+                    float *g_init, int32_t B, int32_t T, int32_t K, float tau, void *stream);
+
 /* ---- fused conv epilogues of the frame VAE ------------------------------------------------- */
 
 /* out[N,C,H*r,W*r] = act(pixel_shuffle_r(in[N,C*r*r,H,W] + bias[C*r*r])), act = ReLU if relu != 0, r in {1,2,..}:

@@ -435,3 +435,41 @@ int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in,
 }
 int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHUNK - 1) / KVAE_EPI_SAMPLES_PER_CHUNK; }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// regime chain of the switching dynamics (regime.h)
+// ---------------------------------------------------------------------------------------------
+#include "regime.h"
+
+__global__ __launch_bounds__(64) void k_regime_fwd(const float *logits, const float *init_logits, const float *gumbel,
+                                                   const float *P, float *y_seq, float *log_q, float *log_p, int T, int K,
+                                                   float tau, int hard) {
+  __shared__ RegimeLds L;
+  regime_fwd_body(logits, init_logits, gumbel, P, y_seq, log_q, log_p, blockIdx.x, T, K, tau, hard, L);
+}
+__global__ __launch_bounds__(64) void k_regime_bwd(const float *logits, const float *init_logits, const float *gumbel,
+                                                   const float *P, const float *y_seq, const float *g_y, const float *g_lq,
+                                                   const float *g_lp, float *g_logits, float *g_init, int T, int K, float tau) {
+  __shared__ RegimeLds L;
+  regime_bwd_body(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, blockIdx.x, T, K, tau, L);
+}
+
+extern "C" {
+int kvae_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, float *y_seq,
+                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, int32_t hard, void *stream) {
+  if (!logits || !init_logits || !gumbel || !P || !y_seq || !log_q || !log_p) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || !(tau > 0.f)) return KVAE_ERR_ARG;
+  k_regime_fwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, T, K, tau, hard);
+  return launch_status("k_regime_fwd");
+}
+int kvae_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, const float *y_seq,
+                    const float *g_y, const float *g_log_q, const float *g_log_p, float *g_logits, float *g_init, int32_t B,
+                    int32_t T, int32_t K, float tau, void *stream) {
+  if (!logits || !init_logits || !gumbel || !P || !y_seq || !g_y || !g_log_q || !g_log_p || !g_logits || !g_init)
+    return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || !(tau > 0.f)) return KVAE_ERR_ARG;
+  k_regime_bwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, init_logits, gumbel, P, y_seq, g_y, g_log_q, g_log_p,
+                                                             g_logits, g_init, T, K, tau);
+  return launch_status("k_regime_bwd");
+}
+}  // extern "C"

@@ -316,3 +316,38 @@ class LstmSequence(torch.autograd.Function):
         g_wih = d2.t() @ x.reshape(Bsz * T, I)
         g_b = d2.sum(0)
         return dx, g_wih, g_whh, g_b, g_b
+
+
+# ------------------------------------------------------------------------------------------------
+# regime chain of the switching dynamics
+# ------------------------------------------------------------------------------------------------
+class RegimeChain(torch.autograd.Function):
+    """(y_seq, log_q, log_p) of the Gumbel-softmax Markov chain (reference switch_dyn_param.py:52-79): one
+    launch forward, one BPTT launch backward instead of T-1 Python iterations of ~10 aten ops."""
+
+    @staticmethod
+    def forward(ctx, logits, init_logits, gumbel, P, tau, hard):
+        logits, init_logits, gumbel, P = (_f32c(t) for t in (logits, init_logits, gumbel, P))
+        Bsz, T, K, _ = logits.shape
+        mk = lambda *s: torch.empty(*s, device=logits.device, dtype=torch.float32)
+        y, lq, lp = mk(Bsz, T, K), mk(Bsz, T), mk(Bsz, T)
+        lib = N.lib_for(logits)
+        lib.check(N.timed("regime_fwd", logits, lambda: lib.dll.kvae_regime_fwd(
+            N.ptr(logits), N.ptr(init_logits), N.ptr(gumbel), N.ptr(P), N.ptr(y), N.ptr(lq), N.ptr(lp), Bsz, T, K,
+            float(tau), int(hard), N.stream_for(logits))), "kvae_regime_fwd")
+        ctx.tau = float(tau)
+        ctx.save_for_backward(logits, init_logits, gumbel, P, y)
+        return y, lq, lp
+
+    @staticmethod
+    def backward(ctx, g_y, g_lq, g_lp):
+        logits, init_logits, gumbel, P, y = ctx.saved_tensors
+        Bsz, T, K, _ = logits.shape
+        z = lambda t, *s: _f32c(t) if t is not None else torch.zeros(*s, device=logits.device, dtype=torch.float32)
+        g_y, g_lq, g_lp = z(g_y, Bsz, T, K), z(g_lq, Bsz, T), z(g_lp, Bsz, T)
+        g_logits, g_init = torch.empty_like(logits), torch.empty_like(init_logits)
+        lib = N.lib_for(logits)
+        lib.check(N.timed("regime_bwd", logits, lambda: lib.dll.kvae_regime_bwd(
+            N.ptr(logits), N.ptr(init_logits), N.ptr(gumbel), N.ptr(P), N.ptr(y), N.ptr(g_y), N.ptr(g_lq), N.ptr(g_lp),
+            N.ptr(g_logits), N.ptr(g_init), Bsz, T, K, ctx.tau, N.stream_for(logits))), "kvae_regime_bwd")
+        return g_logits, g_init, None, None, None, None

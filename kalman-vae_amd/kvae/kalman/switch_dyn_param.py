@@ -11,7 +11,8 @@ import torch.nn as nn
 from torch.distributions import Multinomial
 
 from .. import noise
-from .lgssm_ops import Slots, mix_dynamics
+from .. import _native
+from .lgssm_ops import RegimeChain, Slots, mix_dynamics
 
 
 def _gumbel_softmax(logits, g, tau, hard):
@@ -83,7 +84,12 @@ class SwitchingDynamicsParameter(nn.Module):
             gumbel = -torch.empty(Bsz, T, self.K, device=dev, dtype=dt).exponential_().log()
         else:
             gumbel = gumbel.to(device=dev, dtype=dt)
-        y_seq, self.log_qseq, self.log_pseq = self.regime_chain(logits, init_logits, gumbel, hard=not is_training)
+        if _native.fused_ok(logits) and self.K <= 16:   # one HIP launch (csrc/regime.h) instead of the T-1 step loop
+            P = self.prior.transition_matrix.to(device=dev, dtype=dt)
+            y_seq, self.log_qseq, self.log_pseq = RegimeChain.apply(logits, init_logits, gumbel, P, self.tau,
+                                                                    not is_training)
+        else:
+            y_seq, self.log_qseq, self.log_pseq = self.regime_chain(logits, init_logits, gumbel, hard=not is_training)
         rec, offs, (A_seq, B_seq, Q_seq) = mix_dynamics(y_seq, [self.A, self.B, self.Q])
         self._record, self._slots = rec, Slots(A=offs[0], B=offs[1], Q=offs[2])
         C_seq = self.C[0].expand(Bsz, T, -1, -1)   # emission shared across regimes (switch_dyn_param.py:85-86)

@@ -47,6 +47,11 @@ class KVAE(nn.Module):
         # config noise values are variances
         self.kalman_filter = KalmanFilter(config.noise_transition ** 0.5, config.noise_emission ** 0.5,
                                           torch.zeros(self.z_dim), torch.eye(self.z_dim) * config.init_cov, dynamics)
+        # Optional second HIP stream for the LGSSM chain (set by kvae.train.train.Trainer): the chain is
+        # latency-bound (one wavefront per sequence, 256 of ~8000 wave slots) and independent of the decoder,
+        # so it overlaps with the decoder convolutions in forward AND backward (autograd replays each node
+        # on its forward stream).  compute_loss() joins the streams.
+        self.lgssm_stream = None
 
     # -- VAE halves -----------------------------------------------------------------------------
     def reparameterize(self, mu, var):
@@ -75,8 +80,14 @@ class KVAE(nn.Module):
         if u is None:
             u = torch.zeros(x.shape[0], x.shape[1], self.u_dim, device=x.device, dtype=x.dtype)
         self.kalman_filter.dyn_params.reset_state()
-        (mus_smooth, Sigmas_smooth, mus_filt, Sigmas_filt, mus_pred, Sigmas_pred,
-         A_list, B_list, C_list) = self.kalman_filter.smooth(a_samples, u, mask=mask)
+        side = self.lgssm_stream if (self.training and a_samples.is_cuda) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                smoothed = self.kalman_filter.smooth(a_samples, u, mask=mask)
+        else:
+            smoothed = self.kalman_filter.smooth(a_samples, u, mask=mask)
+        (mus_smooth, Sigmas_smooth, mus_filt, Sigmas_filt, mus_pred, Sigmas_pred, A_list, B_list, C_list) = smoothed
         x_logits = self.decode_sequence(a_samples)
         return {
             "x_recon": self._to_pixels(x_logits) if with_recon else None, "x_logits": x_logits,
@@ -103,8 +114,15 @@ class KVAE(nn.Module):
         vae_elbo, recon, reg = vae_loss(x, x_mu, x_var, a, a_mu, a_var,
                                         scale_reconstruction=self.config.scale_reconstruction, mask=mask,
                                         out_distr=self.config.out_distr, beta=self.beta)
-        elbo_kf = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u,
-                                          A_list, B_list, C_list, mask=mask)
+        side = self.lgssm_stream if (self.training and a.is_cuda) else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                elbo_kf = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u,
+                                                  A_list, B_list, C_list, mask=mask)
+            torch.cuda.current_stream().wait_stream(side)   # join before the two ELBOs are combined
+        else:
+            elbo_kf = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u,
+                                              A_list, B_list, C_list, mask=mask)
         elbo_total = vae_weight * vae_elbo + kf_weight * elbo_kf
         out = {"loss": -elbo_total, "elbo_total": elbo_total, "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
                "recon": recon, "kl": reg}

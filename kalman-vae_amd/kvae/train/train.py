@@ -27,7 +27,7 @@ import torch.distributed as dist
 
 class Trainer:
     def __init__(self, model, lr=7e-3, weight_decay=0.0, grad_clip_norm=10.0, kf_weight=1.0, vae_weight=1.0,
-                 use_graph=True, world_size=1):
+                 use_graph=True, world_size=1, overlap_lgssm=True):
         self.model, self.clip = model, grad_clip_norm
         self.kf_weight, self.vae_weight = kf_weight, vae_weight
         self.world = world_size
@@ -41,6 +41,8 @@ class Trainer:
         on_gpu = dev.type == "cuda"
         self.opt = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
         self.use_graph = bool(use_graph) and on_gpu
+        # the LGSSM chain runs on its own stream next to the decoder convolutions (fork/join inside the graph)
+        model.lgssm_stream = torch.cuda.Stream() if (on_gpu and overlap_lgssm and self.use_graph) else None
         self.graph_fb = self.graph_opt = None
         self.static_x = None
         self.out = {}

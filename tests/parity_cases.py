@@ -147,3 +147,29 @@ def vae_epilogue_vs_torch(DEV, N, C, H, W, r, relu):
     assert torch.equal(out.detach().cpu(), ref.detach())
     assert torch.equal(xd.grad.cpu(), xr.grad)
     assert rel_err(bd.grad.cpu(), br.grad) < 1e-5
+
+
+def regime_vs_torch(DEV, B, T, K, tau, hard):
+    """kvae_regime_fwd/bwd vs the step-by-step torch restatement of switch_dyn_param.py:52-79 (values and grads)."""
+    from kvae.kalman.lgssm_ops import RegimeChain
+    from kvae.kalman.switch_dyn_param import StickyRegimePrior, SwitchingDynamicsParameter
+    g = torch.Generator().manual_seed(B + T + K)
+    logits = torch.randn(B, T, K, K, generator=g)
+    init = torch.randn(B, K, generator=g)
+    gum = -torch.empty(B, T, K).exponential_(generator=g).log()
+    w_y, w_q, w_p = torch.randn(B, T, K, generator=g), torch.randn(B, T, generator=g), torch.randn(B, T, generator=g)
+    dyn = SwitchingDynamicsParameter(torch.eye(4).repeat(K, 1, 1), torch.zeros(K, 4, 4), torch.zeros(K, 2, 4),
+                                     prior=StickyRegimePrior(K, 0.8))
+    dyn.tau = tau
+    lr, ir = logits.clone().requires_grad_(True), init.clone().requires_grad_(True)
+    y, lq, lp = dyn.regime_chain(lr, ir, gum, hard)
+    ((y * w_y).sum() + (lq * w_q).sum() + (lp * w_p).sum()).backward()
+    ld, idv = logits.clone().to(DEV).requires_grad_(True), init.clone().to(DEV).requires_grad_(True)
+    P = dyn.prior.transition_matrix.to(DEV)
+    y2, lq2, lp2 = RegimeChain.apply(ld, idv, gum.to(DEV), P, tau, hard)
+    ((y2 * w_y.to(DEV)).sum() + (lq2 * w_q.to(DEV)).sum() + (lp2 * w_p.to(DEV)).sum()).backward()
+    assert rel_err(y2.detach().cpu(), y.detach()) < 2e-5
+    assert rel_err(lq2.detach().cpu(), lq.detach()) < 2e-5 and rel_err(lp2.detach().cpu(), lp.detach()) < 2e-5
+    ref_lg = lr.grad if lr.grad is not None else torch.zeros_like(logits)   # T == 1: transition logits unused
+    assert (ld.grad.cpu() - ref_lg).abs().max() <= 2e-4 * ref_lg.abs().max() + 1e-12
+    assert rel_err(idv.grad.cpu(), ir.grad) < 2e-4

@@ -158,3 +158,8 @@ def test_lstm_gpu(B, T, I, H):
 @pytest.mark.parametrize("N,C,H,W,r,relu", [(64, 32, 8, 8, 2, True), (7, 1, 16, 16, 2, False), (33, 32, 16, 16, 1, True)])
 def test_vae_epilogue_gpu(N, C, H, W, r, relu):
     parity_cases.vae_epilogue_vs_torch(DEV, N, C, H, W, r, relu)
+
+
+@pytest.mark.parametrize("B,T,K,tau,hard", [(256, 50, 3, 1.0, False), (4, 100, 7, 0.5, False), (3, 10, 3, 0.7, True)])
+def test_regime_gpu(B, T, K, tau, hard):
+    parity_cases.regime_vs_torch(DEV, B, T, K, tau, hard)

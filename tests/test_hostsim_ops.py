@@ -159,3 +159,9 @@ def test_vae_fused_matches_unfused_hostsim():
     finally:
         _native._set_test_backend(saved)
     assert rel_err(mu_f, mu_p) < 1e-6 and rel_err(var_f, var_p) < 1e-6 and rel_err(out_f, out_p) < 1e-6
+
+
+@pytest.mark.parametrize("B,T,K,tau,hard", [(3, 9, 3, 1.0, False), (2, 20, 7, 0.5, False), (2, 6, 3, 0.7, True), (1, 1, 2, 1.0, False)])
+def test_regime_hostsim(B, T, K, tau, hard):
+    import parity_cases
+    parity_cases.regime_vs_torch("cpu", B, T, K, tau, hard)
