@@ -186,9 +186,11 @@ def main():
         times = _native.profile_stop()
         per_unit = algorithmic_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, args.dynamics == "switching")
         per_unit.update(lstm_bytes(cfg.a_dim, cfg.dynamics_hidden_dim))
+        K = args.modes
+        per_unit.update({"regime_fwd": 4 * (K * K + 2 * K + 2), "regime_bwd": 4 * (2 * K * K + 3 * K + 2)})
         for name, ms in times.items():
             avg = sum(ms) / len(ms)
-            nbytes = per_unit[name] * B * T
+            nbytes = per_unit.get(name, 0) * B * T
             chain[name] = {"avg_us": round(1e3 * avg, 2), "algorithmic_bytes": nbytes,
                            "GBps": round(nbytes / (avg * 1e-3) / 1e9, 2)}
         lg = {k: v for k, v in chain.items() if k in ("smooth_fwd", "smooth_bwd", "elbo")}

@@ -48,11 +48,21 @@ class SwitchingDynamicsParameter(nn.Module):
         self.state_seq = None
         self._record = self._slots = None
 
+    def _prior_matrix(self, dev, dt):
+        """Device copy of the sticky prior, made once per device (a host->device copy is not allowed inside
+        hipGraph capture, and the reference re-uploads it on every call, switch_dyn_param.py:65)."""
+        P = self.prior.transition_matrix
+        cache = getattr(self, "_P_cache", None)
+        if cache is None or cache[0] is not P or cache[1].device != dev or cache[1].dtype != dt:
+            cache = (P, P.to(device=dev, dtype=dt))
+            self._P_cache = cache
+        return cache[1]
+
     def regime_chain(self, logits, init_logits, gumbel, hard):
         """Sequential Gumbel-softmax Markov chain (switch_dyn_param.py:52-79).
         Returns y_seq [B,T,K], log_qseq [B,T], log_pseq [B,T]."""
         Bsz, T, K, _ = logits.shape
-        P = self.prior.transition_matrix.to(device=logits.device, dtype=logits.dtype)
+        P = self._prior_matrix(logits.device, logits.dtype)
         y = _gumbel_softmax(init_logits, gumbel[:, 0], self.tau, hard)
         log_q0 = torch.log_softmax(init_logits, dim=-1)
         ys = [y]
@@ -85,7 +95,7 @@ class SwitchingDynamicsParameter(nn.Module):
         else:
             gumbel = gumbel.to(device=dev, dtype=dt)
         if _native.fused_ok(logits) and self.K <= 16:   # one HIP launch (csrc/regime.h) instead of the T-1 step loop
-            P = self.prior.transition_matrix.to(device=dev, dtype=dt)
+            P = self._prior_matrix(dev, dt)
             y_seq, self.log_qseq, self.log_pseq = RegimeChain.apply(logits, init_logits, gumbel, P, self.tau,
                                                                     not is_training)
         else:

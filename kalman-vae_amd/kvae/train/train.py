@@ -127,7 +127,8 @@ def init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl" if dev.type == "cuda" else "gloo", rank=rank, world_size=world)
+        backend = os.environ.get("KVAE_DIST_BACKEND", "nccl" if dev.type == "cuda" else "gloo")   # "nccl" == RCCL
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, dev
 
 
