@@ -309,18 +309,21 @@ namespace kvae {
 
 template <int M>
 struct alignas(16) N4BwdLds {
-  float A[16], Q[16], Bm[4 * ((M + 3) / 4 * 4)], C[8], R[4], u[(M + 3) / 4 * 4], y[4], mk[4];
-  float mu[4], Sig[16], mup[4], Sigp[16];
-  float K[8], S[4], J[16];                     // saved gains of the step (K unmasked)
+  // operands (every array starts on a 16-byte boundary; *T = transposed copy so that columns are 16-byte rows too)
+  float A[16], AT[16], Q[16], Bm[4 * ((M + 3) / 4 * 4)], C[8], R[4], u[(M + 3) / 4 * 4], y[4], mk[4];
+  float mu[4], Sig[16], SigT[16], mup[4], Sigp[16], SpT[16], Sp2[16];
+  float K[8], KT[8], S[4], J[16], JT[16];      // saved gains of the step (K unmasked)
   // filter adjoints
   float gmu[4], gSig[16];                      // carried adjoint of the filtered belief (from step t+1)
-  float gmuT[4], G[16], IKC[16], r[4], gr[4];
-  float gIKC[16], gSp[16], GK[8], gK[8], gC1[8], Z[8], gS0[4], gmp[4];
+  float gmuT[4], G[16], IKC[16], IKCT[16], r[4], gr[4];
+  float gIKC[16], gIKCT[16], gSp[16], gSpF[16], gSpFT[16], GK[8], gK[8], gC1[8], Z[8], gS0[4], gmp[4];
   // smoother adjoints
-  float Sf[16], mus[4], Sigs[16];
-  float gsm[4], gsS[16];                       // carried adjoint of the smoothed belief at t
-  float gM[16], gD[16], gdm[4], aug2[32], gR[16];
+  float Sf[16], mus[4], D2[16];
+  float gsm[4], gM[16];                        // carried adjoint of the smoothed belief at t (gM symmetrised)
+  float gD[16], gdm[4], gJ[16], gR[16], gRT[16];
 };
+
+KV_DEV void st4(float *p, kv4 v) { *reinterpret_cast<kv4 *>(p) = v; }
 
 template <class D>
 KV_DEV void rts_bwd_sweep_n4(const D d, const kvae_lgssm_problem &P, const kvae_lgssm_states &S,
@@ -335,76 +338,98 @@ KV_DEV void rts_bwd_sweep_n4(const D d, const kvae_lgssm_problem &P, const kvae_
     w[n + nn + i] = opt_load(U.mus_pred, bT * n + i);
   }
   KV_PAR(e, nn) {
-    L.gsS[e] = opt_load(U.Sigmas_smooth, bT * nn + e);
+    const int eT = (e & 3) * 4 + (e >> 2);
+    L.gM[e] = 0.5f * (opt_load(U.Sigmas_smooth, bT * nn + e) + opt_load(U.Sigmas_smooth, bT * nn + eT));
     w[n + nn + n + e] = opt_load(U.Sigmas_pred, bT * nn + e);
     gstack_at(G.gA, b, 0)[e] = 0.0f;
   }
   KV_SYNC();
+  // per-lane register prefetch of step t+1's operands and upstream gradients while step t computes
+  #define KV_S16 KV_PF_SLOTS(16)
+  struct RtsPf { float sf[KV_S16], sp[KV_S16], d2[KV_S16], a[KV_S16], jv[KV_S16], mp[KV_S16], ms[KV_S16], u_sf[KV_S16], u_sp[KV_S16],
+                 u_ss[KV_S16], u_ssT[KV_S16], u_mf[KV_S16], u_mp[KV_S16], u_ms[KV_S16]; } pf;
+  auto issue = [&](int t) {
+    const int64_t q = bT + t;
+    for (int s_ = 0; s_ < KV_S16; ++s_) {
+    const int e = (s_ * KV_LANES + KV_LANE) & 15, eT = (e & 3) * 4 + (e >> 2), i = e & 3;
+    const float *Sp = S.Sigmas_pred + (q + 1) * nn, *Ss = S.Sigmas_smooth + (q + 1) * nn;
+    pf.sp[s_] = Sp[e];
+    pf.sf[s_] = S.Sigmas_filt[q * nn + e];
+    pf.d2[s_] = (Ss[e] - pf.sp[s_]) + (Ss[eT] - Sp[eT]);
+    pf.a[s_] = stack_at(P.A, b, t + 1)[e];
+    pf.jv[s_] = S.aux[q * KV_AUX_N4 + 12 + e];
+    pf.mp[s_] = S.mus_pred[(q + 1) * n + i];
+    pf.ms[s_] = S.mus_smooth[(q + 1) * n + i];
+    pf.u_sf[s_] = opt_load(U.Sigmas_filt, q * nn + e);
+    pf.u_sp[s_] = opt_load(U.Sigmas_pred, (q + 1) * nn + e);
+    pf.u_ss[s_] = opt_load(U.Sigmas_smooth, (q + 1) * nn + e);
+    pf.u_ssT[s_] = opt_load(U.Sigmas_smooth, (q + 1) * nn + eT);
+    pf.u_mf[s_] = opt_load(U.mus_filt, q * n + i);
+    pf.u_mp[s_] = opt_load(U.mus_pred, (q + 1) * n + i);
+    pf.u_ms[s_] = opt_load(U.mus_smooth, (q + 1) * n + i);
+    }
+  };
+  if (T >= 2) issue(0);
   for (int t = 0; t + 1 < T; ++t) {
     const int64_t q = bT + t;
-    copy_in(L.Sf, S.Sigmas_filt + q * nn, nn);
-    copy_in(L.Sigp, S.Sigmas_pred + (q + 1) * nn, nn);
-    copy_in(L.A, stack_at(P.A, b, t + 1), nn);
-    copy_in(L.mup, S.mus_pred + (q + 1) * n, n);
-    copy_in(L.mus, S.mus_smooth + (q + 1) * n, n);
-    copy_in(L.Sigs, S.Sigmas_smooth + (q + 1) * nn, nn);
-    copy_in(L.J, S.aux + q * KV_AUX_N4 + 12, nn);
+    // ---- commit the prefetched step (with transposed copies), then prefetch the next one ------------------------------------
+    const RtsPf cur = pf;
+    KV_PAR(e, nn) {
+      const int eT = (e & 3) * 4 + (e >> 2);
+      L.Sf[e] = cur.sf[e / KV_LANES];
+      L.Sigp[e] = cur.sp[e / KV_LANES];
+      L.D2[e] = cur.d2[e / KV_LANES];
+      L.A[e] = cur.a[e / KV_LANES];
+      L.AT[eT] = cur.a[e / KV_LANES];
+      L.J[e] = cur.jv[e / KV_LANES];
+      L.JT[eT] = cur.jv[e / KV_LANES];
+      if (e < n) { L.mup[e] = cur.mp[e / KV_LANES]; L.mus[e] = cur.ms[e / KV_LANES]; }
+    }
+    if (t + 2 < T) issue(t + 1);
     KV_SYNC();
-    // ---- B1: gM, Y1 = gM J (row i and column j per lane), gJ -> aug2 = [Sig_p | gJ^T], gD, gdm -------------------------
+    // ---- B1: Y1 = gM J (row i, column j per lane) -> gJ, gD ; gdm = J^T gsm ------------------------------------------------
     KV_PAR(e, nn) {
       const int i = e >> 2, j = e & 3;
-      float gj = 0.f, gd = 0.f;
-      for (int k = 0; k < n; ++k) {
-        float y_ik = 0.f, y_kj = 0.f;  // Y1[i,k], Y1[k,j]
-        for (int l = 0; l < n; ++l) {
-          y_ik = fmaf(KV_SYM4(L.gsS, i, l), L.J[l * 4 + k], y_ik);
-          y_kj = fmaf(KV_SYM4(L.gsS, k, l), L.J[l * 4 + j], y_kj);
-        }
-        const float dsym = (L.Sigs[j * 4 + k] - L.Sigp[j * 4 + k]) + (L.Sigs[k * 4 + j] - L.Sigp[k * 4 + j]);
-        gj = fmaf(y_ik, dsym, gj);
-        gd = fmaf(L.J[k * 4 + i], y_kj, gd);
-      }
-      gj = fmaf(L.gsm[i], L.mus[j] - L.mup[j], gj);
-      L.aug2[e] = gj;          // gJ, row-major (first 16 floats of aug2)
-      L.gD[e] = gd;
-      L.gM[e] = KV_SYM4(L.gsS, i, j);
-    }
-    KV_PAR(i, n) {
-      float acc = 0.f;
-      for (int k = 0; k < n; ++k) acc = fmaf(L.J[k * 4 + i], L.gsm[k], acc);
-      L.gdm[i] = acc;
+      const M4 Jm = ldm4(L.J), gMm = ldm4(L.gM);
+      const kv4 y_row = vecmat(ld4(L.gM + 4 * i), Jm);                 // Y1[i,:]
+      const kv4 jcj = ld4(L.JT + 4 * j), jci = ld4(L.JT + 4 * i);      // J[:,j], J[:,i]
+      const kv4 y_col = kv4{fma4(gMm.r0, jcj, 0.f), fma4(gMm.r1, jcj, 0.f), fma4(gMm.r2, jcj, 0.f), fma4(gMm.r3, jcj, 0.f)};
+      L.gJ[e] = fmaf(L.gsm[i], L.mus[j] - L.mup[j], fma4(y_row, ld4(L.D2 + 4 * j), 0.f));
+      L.gD[e] = fma4(jci, y_col, 0.f);
+      if (j == 0) L.gdm[i] = fma4(jci, ld4(L.gsm), 0.f);
     }
     KV_SYNC();
-    // ---- B2: gR = Sig_p^{-1} gJ^T: column c of gR solves Sig_p x = gJ[c,:]^T, one system per lane, in registers ----------
+    // ---- B2: gR = Sig_p^{-1} gJ^T, one 4x4 system per lane (registers) ; gRT keeps gR[:,c] as a row ----------------------------
     KV_PAR(c, n) {
-      const kv4 x = solve4(ldm4(L.Sigp), ld4(L.aug2 + 4 * c));
+      const kv4 x = solve4(ldm4(L.Sigp), ld4(L.gJ + 4 * c));
       L.gR[0 * 4 + c] = x.x; L.gR[1 * 4 + c] = x.y; L.gR[2 * 4 + c] = x.z; L.gR[3 * 4 + c] = x.w;
+      st4(L.gRT + 4 * c, x);
     }
     KV_SYNC();
-    // ---- B7: hand-offs to the filter sweep, smoother share of gA, carried adjoint of the smoothed belief at t+1 ---------
+    // ---- B7: hand-offs to the filter sweep, smoother share of gA, carried adjoint of the smoothed belief at t+1 ---------------
     KV_PAR(e, nn) {
-      const int i = e >> 2, j = e & 3;
-      float acc = 0.f, gp = 0.f, ga = 0.f;
-      for (int k = 0; k < n; ++k) {
-        acc = fmaf(L.gR[k * 4 + i], L.A[k * 4 + j], acc);     // (gW A)[i,j]
-        gp = fmaf(L.J[k * 4 + i], L.gR[j * 4 + k], gp);       // (J^T gW)[i,j]
-        ga = fmaf(L.gR[i * 4 + k], L.Sf[k * 4 + j], ga);      // (gW^T Sig_f)[i,j]
-      }
-      w[n + e] = opt_load(U.Sigmas_filt, q * nn + e) + L.gM[e] + acc;
-      w[rec + n + nn + n + e] = opt_load(U.Sigmas_pred, (q + 1) * nn + e) - L.gD[e] - gp;
+      const int i = e >> 2, j = e & 3, eT = j * 4 + i;
+      const float acc = fma4(ld4(L.gRT + 4 * i), ld4(L.AT + 4 * j), 0.f);   // (gW A)[i,j]
+      const float gp = fma4(ld4(L.JT + 4 * i), ld4(L.gR + 4 * j), 0.f);     // (J^T gW)[i,j]
+      const float ga = fma4(ld4(L.gR + 4 * i), ld4(L.Sf + 4 * j), 0.f);     // (gW^T Sig_f)[i,j]  (Sig_f symmetric)
+      const float gm = L.gM[e];
+      w[n + e] = cur.u_sf[e / KV_LANES] + gm + acc;
+      w[rec + n + nn + n + e] = cur.u_sp[e / KV_LANES] - L.gD[e] - gp;
       gstack_at(G.gA, b, t + 1)[e] = ga;
-      L.gsS[e] = opt_load(U.Sigmas_smooth, (q + 1) * nn + e) + L.gD[e];   // gsS is not read in this phase
+      L.gJ[e] = 0.5f * ((cur.u_ss[e / KV_LANES] + L.gD[e]) + (cur.u_ssT[e / KV_LANES] + L.gD[eT]));   // next gM, staged in gJ
     }
     KV_PAR(i, n) {
-      w[i] = opt_load(U.mus_filt, q * n + i) + L.gsm[i];
-      w[rec + n + nn + i] = opt_load(U.mus_pred, (q + 1) * n + i) - L.gdm[i];
-      L.gsm[i] = opt_load(U.mus_smooth, (q + 1) * n + i) + L.gdm[i];      // same lane reads then writes gsm[i]
+      w[i] = cur.u_mf[i / KV_LANES] + L.gsm[i];
+      w[rec + n + nn + i] = cur.u_mp[i / KV_LANES] - L.gdm[i];
+      L.gsm[i] = cur.u_ms[i / KV_LANES] + L.gdm[i];      // same lane reads then writes gsm[i]
     }
     KV_SYNC();
+    KV_PAR(e, nn) { L.gM[e] = L.gJ[e]; }
     w += rec;
   }
+  KV_SYNC();
   const int64_t q = bT + T - 1;
-  KV_PAR(e, nn) { w[n + e] = opt_load(U.Sigmas_filt, q * nn + e) + L.gsS[e]; }
+  KV_PAR(e, nn) { w[n + e] = opt_load(U.Sigmas_filt, q * nn + e) + L.gM[e]; }
   KV_PAR(i, n) { w[i] = opt_load(U.mus_filt, q * n + i) + L.gsm[i]; }
   KV_SYNC();
 }
@@ -413,106 +438,146 @@ template <class D>
 KV_DEV void filter_bwd_sweep_n4(const D d, const kvae_lgssm_problem &P, const kvae_lgssm_states &S,
                                 const kvae_lgssm_input_grads &G, const float *ws, int b, N4BwdLds<D::MMAX> &L) {
   constexpr int n = 4, p = 2, m = D::MMAX, nn = 16, rec = 2 * (n + nn);
+  static_assert(m == 4, "register-blocked path is written for m = 4");
   const int T = P.T;
   const int64_t bT = (int64_t)b * T;
   copy_in(L.R, P.R, p * p);
-  KV_LANE0 { L.mk[0] = 1.0f; }
   KV_PAR(i, n) { L.gmu[i] = 0.0f; }
   KV_PAR(e, nn) { L.gSig[e] = 0.0f; }
   KV_SYNC();
-  for (int t = T - 1; t >= 0; --t) {
+  // per-lane register prefetch of step t-1's operands, saved gains and handed-off adjoints while step t computes
+  struct FbPf { float a[KV_S16], sg[KV_S16], sp[KV_S16], spT[KV_S16], bm[KV_S16], c[KV_S16], kv[KV_S16], s4[KV_S16], mu[KV_S16], mup[KV_S16],
+                u[KV_S16], y[KV_S16], mkv[KV_S16], w_sf[KV_S16], w_sfT[KV_S16], w_sp[KV_S16], w_mf[KV_S16], w_mp[KV_S16]; } pf;
+  auto issue = [&](int t) {
     const int64_t q = bT + t;
     const float *w = ws + q * rec;
-    operands_load(d, P, b, t, L);
-    if (t > 0) {
-      copy_in(L.mu, S.mus_filt + (q - 1) * n, n);
-      copy_in(L.Sig, S.Sigmas_filt + (q - 1) * nn, nn);
-    } else {
-      copy_in(L.mu, P.mu0 + (int64_t)b * P.mu0_sb, n);
-      copy_in(L.Sig, P.Sigma0 + (int64_t)b * P.Sigma0_sb, nn);
+    for (int s_ = 0; s_ < KV_S16; ++s_) {
+    const int e = (s_ * KV_LANES + KV_LANE) & 15, eT = (e & 3) * 4 + (e >> 2), e8 = e & 7, e4 = e & 3, e2 = e & 1;
+    pf.a[s_] = stack_at(P.A, b, t)[e];
+    const float *Sg = t > 0 ? S.Sigmas_filt + (q - 1) * nn : P.Sigma0 + (int64_t)b * P.Sigma0_sb;
+    pf.sg[s_] = Sg[e];
+    const float *Sp = S.Sigmas_pred + q * nn;
+    pf.sp[s_] = Sp[e];
+    pf.spT[s_] = Sp[eT];
+    pf.bm[s_] = stack_at(P.Bm, b, t)[e];
+    pf.c[s_] = stack_at(P.C, b, t)[e8];
+    pf.kv[s_] = S.aux[q * KV_AUX_N4 + e8];
+    pf.s4[s_] = S.aux[q * KV_AUX_N4 + 8 + e4];
+    pf.mu[s_] = t > 0 ? S.mus_filt[(q - 1) * n + e4] : P.mu0[(int64_t)b * P.mu0_sb + e4];
+    pf.mup[s_] = S.mus_pred[q * n + e4];
+    pf.u[s_] = P.U[q * m + e4];
+    pf.y[s_] = P.Y[q * p + e2];
+    pf.mkv[s_] = *mask_addr(P, b, t);
+    pf.w_sf[s_] = w[n + e];
+    pf.w_sfT[s_] = w[n + eT];
+    pf.w_sp[s_] = w[n + nn + n + e];
+    pf.w_mf[s_] = w[e4];
+    pf.w_mp[s_] = w[n + nn + e4];
     }
-    copy_in(L.mup, S.mus_pred + q * n, n);
-    copy_in(L.Sigp, S.Sigmas_pred + q * nn, nn);
-    copy_in(L.K, S.aux + q * KV_AUX_N4, 8);
-    copy_in(L.S, S.aux + q * KV_AUX_N4 + 8, 4);
+  };
+  issue(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t q = bT + t;
+    // ---- commit the prefetched step (with transposed copies), then prefetch the next one ----------------------------------------------
+    const FbPf cur = pf;
+    KV_PAR(e, nn) {
+      const int eT = (e & 3) * 4 + (e >> 2);
+      L.A[e] = cur.a[e / KV_LANES];
+      L.AT[eT] = cur.a[e / KV_LANES];
+      L.Sig[e] = cur.sg[e / KV_LANES];
+      L.SigT[eT] = cur.sg[e / KV_LANES];
+      L.Sigp[e] = cur.sp[e / KV_LANES];
+      L.SpT[eT] = cur.sp[e / KV_LANES];
+      L.Sp2[e] = cur.sp[e / KV_LANES] + cur.spT[e / KV_LANES];
+      L.Bm[e] = cur.bm[e / KV_LANES];
+      if (e < 8) {
+        L.C[e] = cur.c[e / KV_LANES];
+        L.K[e] = cur.kv[e / KV_LANES];                                     // K[i,c] unmasked, e = i*2 + c
+        L.KT[(e & 1) * 4 + (e >> 1)] = cur.kv[e / KV_LANES];
+      }
+      if (e < 4) {
+        L.S[e] = cur.s4[e / KV_LANES];
+        L.mu[e] = cur.mu[e / KV_LANES];
+        L.mup[e] = cur.mup[e / KV_LANES];
+        L.u[e] = cur.u[e / KV_LANES];
+        L.gmuT[e] = L.gmu[e] + cur.w_mf[e / KV_LANES];    // total adjoint of mu_f[t] (gmu was written in P7 of the previous iteration)
+        L.gmp[e] = cur.w_mp[e / KV_LANES];                // handed-off adjoint of mu_p[t], completed in P6
+      }
+      if (e < 2) L.y[e] = cur.y[e / KV_LANES];
+    }
+    KV_LANE0 { L.mk[0] = P.mask ? cur.mkv[0] : 1.0f; }
+    if (t > 0) issue(t - 1);
     KV_SYNC();
     const float mk = L.mk[0];
-    // ---- P1: totals of the incoming adjoints, G = sym(gSig), IKC, r, gr ---------------------------------------------------
+    // ---- P1: totals of the incoming adjoints, G = sym(gSig), IKC (+transpose), r, gr -------------------------------------------------
     KV_PAR(e, nn) {
-      const int i = e >> 2, j = e & 3;
-      L.G[e] = 0.5f * ((L.gSig[e] + w[n + e]) + (L.gSig[j * 4 + i] + w[n + j * 4 + i]));
+      const int i = e >> 2, j = e & 3, eT = j * 4 + i;
+      L.G[e] = 0.5f * ((L.gSig[e] + cur.w_sf[e / KV_LANES]) + (L.gSig[eT] + cur.w_sfT[e / KV_LANES]));
       float acc = 0.f;
-      for (int c = 0; c < p; ++c) acc = fmaf(mk * L.K[i * 2 + c], L.C[c * 4 + j], acc);
-      L.IKC[e] = (i == j ? 1.0f : 0.0f) - acc;
-    }
-    KV_PAR(i, n) { L.gmuT[i] = L.gmu[i] + w[i]; }
-    KV_PAR(c, p) {
-      float acc = 0.f, g = 0.f;
-      for (int k = 0; k < n; ++k) {
-        acc = fmaf(L.C[c * 4 + k], L.mup[k], acc);
-        g = fmaf(mk * L.K[k * 2 + c], L.gmu[k] + w[k], g);
+      acc = fmaf(mk * L.K[i * 2], L.C[j], acc);
+      acc = fmaf(mk * L.K[i * 2 + 1], L.C[4 + j], acc);
+      const float v = (i == j ? 1.0f : 0.0f) - acc;
+      L.IKC[e] = v;
+      L.IKCT[eT] = v;
+      if (e >= 4 && e < 6) {
+        const int c = e - 4;
+        const kv4 kc = ld4(L.KT + 4 * c);
+        const kv4 gm = ld4(L.gmuT);
+        L.r[c] = L.y[c] - fma4(ld4(L.C + 4 * c), ld4(L.mup), 0.f);
+        L.gr[c] = fma4(kv4{mk * kc.x, mk * kc.y, mk * kc.z, mk * kc.w}, gm, 0.f);
       }
-      L.r[c] = L.y[c] - acc;
-      L.gr[c] = g;
     }
     KV_SYNC();
-    // ---- P2: X1 = G IKC (row i, column j per lane) -> gIKC, gSp0 ; GK = G K ------------------------------------------------
+    // ---- P2: X1 = G IKC (row i, column j per lane) -> gIKC (+transpose), gSp0 ; GK = G K ------------------------------------------------
     KV_PAR(e, nn) {
-      const int i = e >> 2, j = e & 3;
-      float gi = 0.f, gs = 0.f;
-      for (int k = 0; k < n; ++k) {
-        float x_ik = 0.f, x_kj = 0.f;
-        for (int l = 0; l < n; ++l) {
-          x_ik = fmaf(L.G[i * 4 + l], L.IKC[l * 4 + k], x_ik);
-          x_kj = fmaf(L.G[k * 4 + l], L.IKC[l * 4 + j], x_kj);
-        }
-        gi = fmaf(x_ik, L.Sigp[j * 4 + k] + L.Sigp[k * 4 + j], gi);
-        gs = fmaf(L.IKC[k * 4 + i], x_kj, gs);
-      }
+      const int i = e >> 2, j = e & 3, eT = j * 4 + i;
+      const M4 Gm = ldm4(L.G), IK = ldm4(L.IKC);
+      const kv4 gi_row = ld4(L.G + 4 * i);
+      const kv4 x_row = vecmat(gi_row, IK);                                   // X1[i,:]
+      const kv4 icj = ld4(L.IKCT + 4 * j);                                    // IKC[:,j]
+      const kv4 x_col = kv4{fma4(Gm.r0, icj, 0.f), fma4(Gm.r1, icj, 0.f), fma4(Gm.r2, icj, 0.f), fma4(Gm.r3, icj, 0.f)};
+      const float gi = fma4(x_row, ld4(L.Sp2 + 4 * j), 0.f);
       L.gIKC[e] = gi;
-      L.gSp[e] = gs + w[n + nn + n + e];
+      L.gIKCT[eT] = gi;
+      L.gSp[e] = fma4(ld4(L.IKCT + 4 * i), x_col, 0.f) + cur.w_sp[e / KV_LANES];
       if (j < p) {
-        float acc = 0.f;
-        for (int k = 0; k < n; ++k) acc = fmaf(L.G[i * 4 + k], mk * L.K[k * 2 + j], acc);
-        L.GK[i * 2 + j] = acc;
+        const kv4 kc = ld4(L.KT + 4 * j);
+        L.GK[i * 2 + j] = fma4(gi_row, kv4{mk * kc.x, mk * kc.y, mk * kc.z, mk * kc.w}, 0.f);
       }
     }
     KV_SYNC();
-    // ---- P3: gK, gC1 ------------------------------------------------------------------------------------------------------------
+    // ---- P3: gK, gC1 ------------------------------------------------------------------------------------------------------------------------
     KV_PAR(e, n * p) {
       const int i = e >> 1, c = e & 1;
       float acc = 0.f;
       for (int k = 0; k < p; ++k) acc = fmaf(L.GK[i * 2 + k], L.R[c * 2 + k] + L.R[k * 2 + c], acc);
-      for (int k = 0; k < n; ++k) acc = fmaf(-L.gIKC[i * 4 + k], L.C[c * 4 + k], acc);
+      const kv4 gik = ld4(L.gIKC + 4 * i), cc = ld4(L.C + 4 * c);
+      acc = fmaf(-gik.x, cc.x, acc); acc = fmaf(-gik.y, cc.y, acc); acc = fmaf(-gik.z, cc.z, acc); acc = fmaf(-gik.w, cc.w, acc);
       acc = fmaf(L.gmuT[i], L.r[c], acc);
       L.gK[e] = acc;
       const int c2 = e >> 2, j2 = e & 3;   // the same 8 lanes also produce gC1[c2,j2] = -(K^T gIKC)
-      float a2 = 0.f;
-      for (int k = 0; k < n; ++k) a2 = fmaf(mk * L.K[k * 2 + c2], L.gIKC[k * 4 + j2], a2);
-      L.gC1[e] = -a2;
+      const kv4 kc = ld4(L.KT + 4 * c2);
+      L.gC1[e] = -fma4(kv4{mk * kc.x, mk * kc.y, mk * kc.z, mk * kc.w}, ld4(L.gIKCT + 4 * j2), 0.f);
     }
     KV_SYNC();
-    // ---- P4: Z = solve(S^T, mask gK^T), one column per lane ------------------------------------------------------------------------
+    // ---- P4: Z = solve(S^T, mask gK^T), one column per lane -----------------------------------------------------------------------------------
     KV_PAR(j, n) {
-      const Sol2 z = solve2(L.S[0], L.S[2], L.S[1], L.S[3], mk * L.gK[j * 2], mk * L.gK[j * 2 + 1]);
+      const kv4 s = ld4(L.S);
+      const Sol2 z = solve2(s.x, s.z, s.y, s.w, mk * L.gK[j * 2], mk * L.gK[j * 2 + 1]);
       L.Z[j] = z.x0;
       L.Z[4 + j] = z.x1;
     }
     KV_SYNC();
-    // ---- P5: gS0 = sym(-Z Kt^T), Kt = unmasked K^T ---------------------------------------------------------------------------------------
+    // ---- P5: gS0 = sym(-Z Kt^T), Kt = unmasked K^T --------------------------------------------------------------------------------------------------
     KV_PAR(e, p * p) {
       const int a = e >> 1, c = e & 1;
-      float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < n; ++k) {
-        s1 = fmaf(L.Z[a * 4 + k], L.K[k * 2 + c], s1);
-        s2 = fmaf(L.Z[c * 4 + k], L.K[k * 2 + a], s2);
-      }
+      const float s1 = fma4(ld4(L.Z + 4 * a), ld4(L.KT + 4 * c), 0.f), s2 = fma4(ld4(L.Z + 4 * c), ld4(L.KT + 4 * a), 0.f);
       L.gS0[e] = -0.5f * (s1 + s2);
     }
     KV_SYNC();
-    // ---- P6: gSp (final) ; gC ; gmp ; gY -------------------------------------------------------------------------------------------------------
+    // ---- P6: gSp (final, + transpose) ; gC ; gmp ; gY ------------------------------------------------------------------------------------------------------
     KV_PAR(e, nn) {
-      const int i = e >> 2, j = e & 3;
+      const int i = e >> 2, j = e & 3, eT = j * 4 + i;
       float acc = L.gSp[e];
       for (int k = 0; k < p; ++k) {
         float gcp = 0.f;  // gCP[k,j] = (gS0 C)[k,j]
@@ -520,68 +585,53 @@ KV_DEV void filter_bwd_sweep_n4(const D d, const kvae_lgssm_problem &P, const kv
         acc = fmaf(L.Z[k * 4 + i], L.C[k * 4 + j], acc);
         acc = fmaf(L.C[k * 4 + i], gcp, acc);
       }
-      L.gIKC[e] = acc;   // final gSp parked in gIKC (dead after P3) so that gSp is not read and written in one phase
+      L.gSpF[e] = acc;
+      L.gSpFT[eT] = acc;
       if (G.gQ.ptr) gstack_at(G.gQ, b, t)[e] = acc;
-    }
-    KV_PAR(e, p * n) {
-      const int c = e >> 2, j = e & 3;
-      float acc = L.gC1[e];
-      for (int k = 0; k < n; ++k) {
-        float gcp = 0.f;  // gCP[c,k]
-        for (int cc = 0; cc < p; ++cc) gcp = fmaf(L.gS0[c * 2 + cc], L.C[cc * 4 + k], gcp);
-        acc = fmaf(L.Z[c * 4 + k], L.Sigp[k * 4 + j], acc);
-        acc = fmaf(gcp, L.Sigp[j * 4 + k], acc);
+      if (e < 8) {   // lanes 0..7 also produce gC[c,jj]
+        const int c = e >> 2, jj = e & 3;
+        const kv4 c0 = ld4(L.C), c1 = ld4(L.C + 4);
+        const kv4 sptj = ld4(L.SpT + 4 * jj);          // Sig_p[:,jj]
+        const float g0 = L.gS0[c * 2], g1 = L.gS0[c * 2 + 1];
+        const kv4 gcp = kv4{fmaf(g1, c1.x, g0 * c0.x), fmaf(g1, c1.y, g0 * c0.y), fmaf(g1, c1.z, g0 * c0.z), fmaf(g1, c1.w, g0 * c0.w)};
+        float a2 = L.gC1[e];
+        a2 = fma4(ld4(L.Z + 4 * c), sptj, a2);                   // (Z Sig_p)[c,jj]
+        a2 = fma4(gcp, ld4(L.Sigp + 4 * jj), a2);                // (gCP Sig_p^T)[c,jj]
+        a2 = fmaf(g0, fma4(c0, sptj, 0.f), a2);                  // gS0[c,0] (C Sig_p)[0,jj]
+        a2 = fmaf(g1, fma4(c1, sptj, 0.f), a2);
+        a2 = fmaf(-L.gr[c], L.mup[jj], a2);
+        gstack_at(G.gC, b, t)[e] = a2;
+      } else if (e < 12) {
+        const int ii = e - 8;
+        float a3 = L.gmuT[ii] + L.gmp[ii];   // gmp holds the handed-off adjoint of mu_p until here (same lane rewrites it)
+        a3 = fmaf(-L.C[ii], L.gr[0], a3);
+        a3 = fmaf(-L.C[4 + ii], L.gr[1], a3);
+        L.gmp[ii] = a3;
+      } else if (e < 14) {
+        G.gY[q * p + (e - 12)] = L.gr[e - 12];
       }
-      for (int k = 0; k < p; ++k) {
-        float cp = 0.f;  // CP[k,j] = (C Sig_p)[k,j]
-        for (int l = 0; l < n; ++l) cp = fmaf(L.C[k * 4 + l], L.Sigp[l * 4 + j], cp);
-        acc = fmaf(L.gS0[c * 2 + k], cp, acc);
-      }
-      acc = fmaf(-L.gr[c], L.mup[j], acc);
-      gstack_at(G.gC, b, t)[e] = acc;
     }
-    KV_PAR(i, n) {
-      float acc = L.gmuT[i] + w[n + nn + i];
-      for (int k = 0; k < p; ++k) acc = fmaf(-L.C[k * 4 + i], L.gr[k], acc);
-      L.gmp[i] = acc;
-    }
-    KV_PAR(c, p) { G.gY[q * p + c] = L.gr[c]; }
     KV_SYNC();
-    // ---- P7: gA, carried adjoints of step t-1, gB, gU --------------------------------------------------------------------------------------------
-    const float *gSpF = L.gIKC;
+    // ---- P7: gA, carried adjoints of step t-1, gB, gU --------------------------------------------------------------------------------------------------------
     KV_PAR(e, nn) {
       const int i = e >> 2, j = e & 3;
+      const M4 Am = ldm4(L.A), gS = ldm4(L.gSpF);
+      const kv4 sig_colj = ld4(L.SigT + 4 * j), sig_rowj = ld4(L.Sig + 4 * j);
+      const kv4 as_col = kv4{fma4(Am.r0, sig_colj, 0.f), fma4(Am.r1, sig_colj, 0.f), fma4(Am.r2, sig_colj, 0.f), fma4(Am.r3, sig_colj, 0.f)};  // (A Sig)[:,j]
+      const kv4 gas_row = vecmat(ld4(L.gSpF + 4 * i), Am);                                                     // (gSp A)[i,:]
+      const kv4 atj = ld4(L.AT + 4 * j);
+      const kv4 gas_col = kv4{fma4(gS.r0, atj, 0.f), fma4(gS.r1, atj, 0.f), fma4(gS.r2, atj, 0.f), fma4(gS.r3, atj, 0.f)};                     // (gSp A)[:,j]
       float acc = gstack_at(G.gA, b, t)[e];
-      float gs = 0.f;
-      for (int k = 0; k < n; ++k) {
-        float as_kj = 0.f, gas_ik = 0.f, gas_kj = 0.f;  // (A Sig)[k,j], (gSp A)[i,k], (gSp A)[k,j]
-        for (int l = 0; l < n; ++l) {
-          as_kj = fmaf(L.A[k * 4 + l], L.Sig[l * 4 + j], as_kj);
-          gas_ik = fmaf(gSpF[i * 4 + l], L.A[l * 4 + k], gas_ik);
-          gas_kj = fmaf(gSpF[k * 4 + l], L.A[l * 4 + j], gas_kj);
-        }
-        acc = fmaf(gSpF[k * 4 + i], as_kj, acc);
-        acc = fmaf(gas_ik, L.Sig[j * 4 + k], acc);
-        gs = fmaf(L.A[k * 4 + i], gas_kj, gs);
-      }
+      acc = fma4(ld4(L.gSpFT + 4 * i), as_col, acc);
+      acc = fma4(gas_row, sig_rowj, acc);
       acc = fmaf(L.gmp[i], L.mu[j], acc);
       gstack_at(G.gA, b, t)[e] = acc;
-      L.gSig[e] = gs;   // gSig was last read in P1
-    }
-    KV_PAR(i, n) {
-      float acc = 0.f;
-      for (int k = 0; k < n; ++k) acc = fmaf(L.A[k * 4 + i], L.gmp[k], acc);
-      L.gmu[i] = acc;   // gmu was last read in P1
-    }
-    KV_PAR(e, n * m) {
-      const int i = e / m, j = e - i * m;
-      gstack_at(G.gB, b, t)[e] = L.gmp[i] * L.u[j];
-    }
-    if (G.gU) {
-      KV_PAR(i, m) {
-        float acc = 0.f;
-        for (int k = 0; k < n; ++k) acc = fmaf(L.Bm[k * m + i], L.gmp[k], acc);
-        G.gU[q * m + i] = acc;
+      L.gSig[e] = fma4(ld4(L.AT + 4 * i), gas_col, 0.f);   // gSig was last read in P1
+      gstack_at(G.gB, b, t)[e] = L.gmp[i] * L.u[j];        // m == 4
+      if (j == 0) L.gmu[i] = fma4(ld4(L.AT + 4 * i), ld4(L.gmp), 0.f);   // gmu was last read in P1
+      if (j == 1 && G.gU) {
+        const kv4 g4 = ld4(L.gmp);
+        G.gU[q * m + i] = fmaf(L.Bm[12 + i], g4.w, fmaf(L.Bm[8 + i], g4.z, fmaf(L.Bm[4 + i], g4.y, L.Bm[i] * g4.x)));
       }
     }
     KV_SYNC();
