@@ -167,6 +167,21 @@ int kvae_regime_bwd(const float *logits, const float *init_logits, const float *
                     const float *y_seq, const float *g_y, const float *g_log_q, const float *g_log_p, float *g_logits,
                     float *g_init, int32_t B, int32_t T, int32_t K, float tau, void *stream);
 
+/* ---- bidirectional GRU of the regime posterior ("switching" dynamics) ------------------------- */
+
+/* nn.GRU(I -> H, bidirectional, batch_first) from zero states (switch_dyn_param.py:118,123): x [B,T,I]; per direction
+ * d in {0 forward, 1 reverse} w_ih[d] [3H,I], w_hh[d] [3H,H], b_ih[d], b_hh[d] [3H] (torch gate order r,z,n).
+ * Outputs h_seq [B,T,2H] and gates [2,B,T,4H] = (r,z,n,W_hn h + b_hn) kept for the backward.
+ * Only (H, I) = (50, 2) is built (KVAEConfig defaults); other shapes return KVAE_ERR_DIMS. */
+int kvae_bigru_fwd(const float *x, const float *const w_ih[2], const float *const w_hh[2], const float *const b_ih[2],
+                   const float *const b_hh[2], float *h_seq, float *gates, int32_t B, int32_t T, int32_t I, int32_t H,
+                   void *stream);
+/* BPTT: g_h [B,T,2H] -> d_pre_i, d_pre_h [2,B,T,3H] and dx [2,B,T,I] (sum the two directions for dL/dx).
+ * Parameter gradients are GEMMs: dW_ih[d] = d_pre_i[d]^T x, dW_hh[d] = d_pre_h[d]^T h_prev[d], biases = column sums. */
+int kvae_bigru_bwd(const float *g_h, const float *gates, const float *h_seq, const float *const w_ih[2],
+                   const float *const w_hh[2], float *d_pre_i, float *d_pre_h, float *dx, int32_t B, int32_t T,
+                   int32_t I, int32_t H, void *stream);
+
 /* ---- fused conv epilogues of the frame VAE ------------------------------------------------- */
 
 /* out[N,C,H*r,W*r] = act(pixel_shuffle_r(in[N,C*r*r,H,W] + bias[C*r*r])), act = ReLU if relu != 0, r in {1,2,..}:

@@ -473,3 +473,33 @@ int kvae_regime_bwd(const float *logits, const float *init_logits, const float *
   return launch_status("k_regime_bwd");
 }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// bidirectional GRU of the regime posterior (gru_fast.h)
+// ---------------------------------------------------------------------------------------------
+#include "gru_fast.h"
+
+extern "C" {
+int kvae_bigru_fwd(const float *x, const float *const w_ih[2], const float *const w_hh[2], const float *const b_ih[2],
+                   const float *const b_hh[2], float *h_seq, float *gates, int32_t B, int32_t T, int32_t I, int32_t H,
+                   void *stream) {
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !h_seq || !gates) return KVAE_ERR_NULL;
+  for (int d = 0; d < 2; ++d)
+    if (!w_ih[d] || !w_hh[d] || !b_ih[d] || !b_hh[d]) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || H != 50 || I != 2) return KVAE_ERR_DIMS;
+  const GruWeights wf{w_ih[0], w_hh[0], b_ih[0], b_hh[0]}, wb{w_ih[1], w_hh[1], b_ih[1], b_hh[1]};
+  k_gru_fwd_fast<50, 2><<<dim3(B, 2), dim3(256), 0, (hipStream_t)stream>>>(x, wf, wb, h_seq, gates, B, T);
+  return launch_status("k_gru_fwd_fast");
+}
+int kvae_bigru_bwd(const float *g_h, const float *gates, const float *h_seq, const float *const w_ih[2],
+                   const float *const w_hh[2], float *d_pre_i, float *d_pre_h, float *dx, int32_t B, int32_t T, int32_t I,
+                   int32_t H, void *stream) {
+  if (!g_h || !gates || !h_seq || !w_ih || !w_hh || !d_pre_i || !d_pre_h || !dx) return KVAE_ERR_NULL;
+  for (int d = 0; d < 2; ++d)
+    if (!w_ih[d] || !w_hh[d]) return KVAE_ERR_NULL;
+  if (B < 1 || T < 1 || H != 50 || I != 2) return KVAE_ERR_DIMS;
+  const GruWeights wf{w_ih[0], w_hh[0], nullptr, nullptr}, wb{w_ih[1], w_hh[1], nullptr, nullptr};
+  k_gru_bwd_fast<50, 2><<<dim3(B, 2), dim3(192), 0, (hipStream_t)stream>>>(g_h, gates, h_seq, wf, wb, d_pre_i, d_pre_h, dx, B, T);
+  return launch_status("k_gru_bwd_fast");
+}
+}  // extern "C"

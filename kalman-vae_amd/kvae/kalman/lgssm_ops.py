@@ -351,3 +351,52 @@ class RegimeChain(torch.autograd.Function):
             N.ptr(logits), N.ptr(init_logits), N.ptr(gumbel), N.ptr(P), N.ptr(y), N.ptr(g_y), N.ptr(g_lq), N.ptr(g_lp),
             N.ptr(g_logits), N.ptr(g_init), Bsz, T, K, ctx.tau, N.stream_for(logits))), "kvae_regime_bwd")
         return g_logits, g_init, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# bidirectional GRU of the regime posterior
+# ------------------------------------------------------------------------------------------------
+def _ptr2(a, b):
+    return (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+
+
+class BiGruSequence(torch.autograd.Function):
+    """h_seq [B,T,2H] = nn.GRU(bidirectional, batch_first)(x) from zero states (reference switch_dyn_param.py:118,123):
+    one launch for both directions forward, one BPTT launch backward, parameter gradients as GEMMs."""
+    SUPPORTED = (50, 2)   # (hidden, input): the shape csrc/gru_fast.h is instantiated for
+
+    @staticmethod
+    def forward(ctx, x, wi0, wh0, bi0, bh0, wi1, wh1, bi1, bh1):
+        x = _f32c(x)
+        ws = [_f32c(t) for t in (wi0, wh0, bi0, bh0, wi1, wh1, bi1, bh1)]
+        Bsz, T, I = x.shape
+        H = ws[1].shape[1]
+        h = torch.empty(Bsz, T, 2 * H, device=x.device, dtype=torch.float32)
+        gates = torch.empty(2, Bsz, T, 4 * H, device=x.device, dtype=torch.float32)
+        lib = N.lib_for(x)
+        lib.check(N.timed("bigru_fwd", x, lambda: lib.dll.kvae_bigru_fwd(
+            N.ptr(x), _ptr2(ws[0], ws[4]), _ptr2(ws[1], ws[5]), _ptr2(ws[2], ws[6]), _ptr2(ws[3], ws[7]), N.ptr(h),
+            N.ptr(gates), Bsz, T, I, H, N.stream_for(x))), "kvae_bigru_fwd")
+        ctx.save_for_backward(x, ws[0], ws[1], ws[4], ws[5], h, gates)
+        return h
+
+    @staticmethod
+    def backward(ctx, g_h):
+        x, wi0, wh0, wi1, wh1, h, gates = ctx.saved_tensors
+        g_h = _f32c(g_h)
+        Bsz, T, I = x.shape
+        H = wh0.shape[1]
+        mk = lambda *s: torch.empty(*s, device=x.device, dtype=torch.float32)
+        dpi, dph, dx = mk(2, Bsz, T, 3 * H), mk(2, Bsz, T, 3 * H), mk(2, Bsz, T, I)
+        lib = N.lib_for(x)
+        lib.check(N.timed("bigru_bwd", x, lambda: lib.dll.kvae_bigru_bwd(
+            N.ptr(g_h), N.ptr(gates), N.ptr(h), _ptr2(wi0, wi1), _ptr2(wh0, wh1), N.ptr(dpi), N.ptr(dph), N.ptr(dx),
+            Bsz, T, I, H, N.stream_for(x))), "kvae_bigru_bwd")
+        x2 = x.reshape(Bsz * T, I)
+        zero = h.new_zeros(Bsz, 1, H)
+        hp = (torch.cat([zero, h[:, :-1, :H]], 1), torch.cat([h[:, 1:, H:], zero], 1))   # h_{prev} per direction
+        out = [dx.sum(0)]
+        for d in (0, 1):
+            di, dh = dpi[d].reshape(Bsz * T, 3 * H), dph[d].reshape(Bsz * T, 3 * H)
+            out += [di.t() @ x2, dh.t() @ hp[d].reshape(Bsz * T, H), di.sum(0), dh.sum(0)]
+        return tuple(out)

@@ -12,7 +12,7 @@ from torch.distributions import Multinomial
 
 from .. import noise
 from .. import _native
-from .lgssm_ops import RegimeChain, Slots, mix_dynamics
+from .lgssm_ops import BiGruSequence, RegimeChain, Slots, mix_dynamics
 
 
 def _gumbel_softmax(logits, g, tau, hard):
@@ -141,6 +141,13 @@ class MarkovVariationalRegimePosterior(nn.Module):
         self.init_head = nn.Linear(2 * hidden_size, K)
 
     def forward(self, a_seq):
-        h_seq, _ = self.bigru(a_seq)
+        g = self.bigru
+        if a_seq.is_cuda and a_seq.dtype == torch.float32 and (g.hidden_size, g.input_size) == BiGruSequence.SUPPORTED:
+            # hand-written HIP recurrence (csrc/gru_fast.h): both directions in one launch, hipGraph-capturable
+            h_seq = BiGruSequence.apply(a_seq, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+                                        g.weight_ih_l0_reverse, g.weight_hh_l0_reverse, g.bias_ih_l0_reverse,
+                                        g.bias_hh_l0_reverse)
+        else:   # other shapes / host tensors: PyTorch (MIOpen) GRU
+            h_seq, _ = self.bigru(a_seq)
         logits = self.linear_head(h_seq).unflatten(-1, (self.K, self.K))
         return logits, self.init_head(h_seq[:, 0])

@@ -262,3 +262,12 @@ int kvae_regime_bwd(const float *logits, const float *init_logits, const float *
   return KVAE_OK;
 }
 }
+
+// The bidirectional GRU has only the register-resident gfx950 kernels (gru_fast.h); the host simulation reports the
+// shape as unsupported so that the Python side keeps nn.GRU on host tensors.
+extern "C" {
+int kvae_bigru_fwd(const float *, const float *const *, const float *const *, const float *const *, const float *const *,
+                   float *, float *, int32_t, int32_t, int32_t, int32_t, void *) { return KVAE_ERR_DIMS; }
+int kvae_bigru_bwd(const float *, const float *, const float *, const float *const *, const float *const *, float *, float *,
+                   float *, int32_t, int32_t, int32_t, int32_t, void *) { return KVAE_ERR_DIMS; }
+}

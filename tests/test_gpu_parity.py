@@ -163,3 +163,25 @@ def test_vae_epilogue_gpu(N, C, H, W, r, relu):
 @pytest.mark.parametrize("B,T,K,tau,hard", [(256, 50, 3, 1.0, False), (4, 100, 7, 0.5, False), (3, 10, 3, 0.7, True)])
 def test_regime_gpu(B, T, K, tau, hard):
     parity_cases.regime_vs_torch(DEV, B, T, K, tau, hard)
+
+
+@pytest.mark.parametrize("B,T", [(256, 50), (3, 7), (2, 1)])
+def test_bigru_gpu(B, T):
+    """kvae_bigru_fwd/bwd vs torch.nn.GRU(bidirectional) on the CPU: values and every gradient."""
+    from kvae.kalman.lgssm_ops import BiGruSequence
+    torch.manual_seed(B + T)
+    ref = torch.nn.GRU(2, 50, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, 2)
+    wgt = torch.randn(B, T, 100)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr)[0] * wgt).sum().backward()
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+             "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    params = [getattr(ref, n).detach().clone().to(DEV).requires_grad_(True) for n in names]
+    xd = x.clone().to(DEV).requires_grad_(True)
+    h = BiGruSequence.apply(xd, *params)
+    (h * wgt.to(DEV)).sum().backward()
+    assert rel_err(h.detach().cpu(), ref(x)[0].detach()) < 2e-5
+    assert rel_err(xd.grad.cpu(), xr.grad) < 2e-4
+    for n, got in zip(names, params):
+        assert rel_err(got.grad.cpu(), getattr(ref, n).grad) < 2e-4, n
