@@ -193,13 +193,21 @@ def main():
             nbytes = per_unit.get(name, 0) * B * T
             chain[name] = {"avg_us": round(1e3 * avg, 2), "algorithmic_bytes": nbytes,
                            "GBps": round(nbytes / (avg * 1e-3) / 1e9, 2)}
+        traffic = {}
+        try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same config only)
+            if (B, T, cfg.z_dim, args.dynamics, args.modes) == (256, 50, 4, "lstm", 3):
+                traffic = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        except Exception:
+            traffic = {}
         lg = {k: v for k, v in chain.items() if k in ("smooth_fwd", "smooth_bwd", "elbo")}
         if lg:
             dom = max(lg, key=lambda k: lg[k]["avg_us"])
             ach = chain[dom]["GBps"]
-            roofline = {"kernel": {"smooth_fwd": "k_smooth_fwd", "smooth_bwd": "k_smooth_bwd", "elbo": "k_elbo(+probe)"}[dom],
+            n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
+            roofline = {"kernel": {"smooth_fwd": "k_smooth_fwd_n4" if n4 else "k_smooth_fwd",
+                                   "smooth_bwd": "k_smooth_bwd_n4" if n4 else "k_smooth_bwd", "elbo": "k_elbo(+probe)"}[dom],
                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom),
                         "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["avg_us"],
                         "note": "latency-bound at this size by construction: T-deep dependent recursion, one wavefront per sequence"}
             tot_us = sum(c["avg_us"] for c in lg.values())

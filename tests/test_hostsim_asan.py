@@ -1,0 +1,39 @@
+"""Run a slice of the host-simulated kernels under AddressSanitizer + UBSan (GPU sanitizers are unavailable on the
+pool, so the CPU build of the kernel bodies is the sanitizer target).  Executed in a subprocess with libasan
+preloaded; any heap/stack overflow or UB in the bodies aborts it."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+SCRIPT = r"""
+import sys
+sys.path[:0] = [%(root)r, %(root)r + "/kalman-vae_amd", %(root)r + "/tests"]
+import torch
+from kvae import _native
+from hostsim.build import build
+_native._set_test_backend(_native.LgssmLib(build(sanitize=True)))
+import parity_cases
+for dims in ((3, 9, 4, 4, 2, 3), (2, 7, 3, 2, 1, 2), (2, 5, 16, 16, 2, 1), (1, 1, 4, 4, 2, 3)):
+    parity_cases.vs_oracle_random("cpu", *dims)
+parity_cases.safe_cholesky_levels("cpu")
+parity_cases.lstm_vs_torch("cpu", 2, 5, 2, 50)
+parity_cases.regime_vs_torch("cpu", 2, 6, 3, 0.7, False)
+parity_cases.vae_epilogue_vs_torch("cpu", 2, 3, 4, 4, 2, True)
+print("ASAN-OK")
+"""
+
+
+def test_hostsim_under_asan():
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not Path(asan).exists():
+        pytest.skip("libasan not available")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1",
+               OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": str(ROOT)}], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert "ASAN-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
