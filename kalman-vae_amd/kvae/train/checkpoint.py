@@ -1,0 +1,40 @@
+"""Checkpoints interchangeable with the reference's `Checkpointer` (kvae/train/utils.py:165-210 there): the payload is
+{epoch, model_state, optimizer_state, train_loss, val_loss}, files are `kvae-best.pt` and `kvae-ckpt-epoch=NNN.pt`,
+and `model_state` uses the same state_dict keys, so either side loads the other's files."""
+from pathlib import Path
+
+import torch
+
+
+class Checkpointer:
+    def __init__(self, checkpoint_dir, ckpt_every: int = 0):
+        self.checkpoint_dir = Path(checkpoint_dir)
+        self.ckpt_every = ckpt_every
+        self.best_val = float("inf")
+        self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
+
+    @staticmethod
+    def payload(model, optimizer, epoch, train_loss, val_loss):
+        return {"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict(),
+                "train_loss": train_loss, "val_loss": val_loss}
+
+    def save_checkpoint(self, path, model, optimizer, epoch, train_loss, val_loss):
+        torch.save(self.payload(model, optimizer, epoch, train_loss, val_loss), path)
+
+    def save_checkpoints(self, train_loss, val_loss, model, optimizer, epoch):
+        if val_loss < self.best_val:
+            self.best_val = val_loss
+            self.save_checkpoint(self.checkpoint_dir / "kvae-best.pt", model, optimizer, epoch, train_loss, val_loss)
+        if self.ckpt_every > 0 and epoch % self.ckpt_every == 0:
+            self.save_checkpoint(self.checkpoint_dir / f"kvae-ckpt-epoch={epoch:03d}.pt", model, optimizer, epoch,
+                                 train_loss, val_loss)
+
+
+def load_checkpoint(path, model, optimizer=None, map_location="cpu"):
+    """Load a checkpoint written by this Checkpointer or by the reference's (tensors only: weights_only=True).
+    Returns the payload (without the state dicts) — note the reference itself has no resume code (train.py)."""
+    payload = torch.load(path, map_location=map_location, weights_only=True)
+    model.load_state_dict(payload["model_state"], strict=True)
+    if optimizer is not None and "optimizer_state" in payload:
+        optimizer.load_state_dict(payload["optimizer_state"])
+    return {k: v for k, v in payload.items() if k not in ("model_state", "optimizer_state")}
