@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 2
+#define KVAE_ABI_VERSION 3
 
 typedef enum {
   KVAE_OK = 0,
@@ -119,10 +119,12 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
  * 0..4 (jitter 1e-6 * 10^level) at which every factorisation succeeds, or 5 = diagonal fallback.
  * If `g` / g_mus / g_Sigmas are non-NULL the gradients of SUM(terms) w.r.t. mus_smooth,
  * Sigmas_smooth and the problem inputs are written as well (unit upstream; the caller scales).
- * eps: [B,T,n] standard normal draws. chol_levels: 2 ints of device scratch (zeroed by the call). */
+ * eps: [B,T,n] standard normal draws. chol_levels: 2 ints of device scratch (zeroed by the call).
+ * ws_lz: optional scratch [B,T,n*n+n]: the probe launch parks its level-0 factor and sample there so that the main
+ * launch does not re-factorise neighbouring steps (NULL = always recompute). */
 int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth,
-                    const float *eps, float *terms, int32_t *chol_levels, float *g_mus, float *g_Sigmas,
-                    const kvae_lgssm_input_grads *g, void *stream);
+                    const float *eps, float *terms, int32_t *chol_levels, float *ws_lz, float *g_mus,
+                    float *g_Sigmas, const kvae_lgssm_input_grads *g, void *stream);
 
 /* ---- mixture-of-K dynamics ---------------------------------------------------------------- */
 

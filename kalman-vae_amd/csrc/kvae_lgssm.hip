@@ -77,21 +77,22 @@ __global__ __launch_bounds__(64) void k_smooth_bwd_n4(kvae_lgssm_problem P, kvae
 }
 
 template <class D>
-__global__ __launch_bounds__(64) void k_elbo_probe(kvae_lgssm_problem P, const float *Sig_s, int32_t *levels) {
+__global__ __launch_bounds__(64) void k_elbo_probe(kvae_lgssm_problem P, const float *Sig_s, const float *mus,
+                                                   const float *eps, float *ws, int32_t *levels) {
   __shared__ ElboLds<D> L;
   const D d(P.n, P.m, P.p);
   const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
-  elbo_probe_body(d, P, Sig_s, levels, b, t, L);
+  elbo_probe_body(d, P, Sig_s, mus, eps, ws, levels, b, t, L);
 }
 
 template <class D>
 __global__ __launch_bounds__(64) void k_elbo(kvae_lgssm_problem P, const float *mus, const float *Sigs,
-                                             const float *eps, float *terms, const int32_t *levels, float *g_mus,
-                                             float *g_Sigs, kvae_lgssm_input_grads G, int have_g) {
+                                             const float *eps, float *terms, const int32_t *levels, const float *ws,
+                                             float *g_mus, float *g_Sigs, kvae_lgssm_input_grads G, int have_g) {
   __shared__ ElboLds<D> L;
   const D d(P.n, P.m, P.p);
   const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
-  elbo_body(d, P, mus, Sigs, eps, terms, levels, g_mus, g_Sigs, have_g ? &G : nullptr, b, t, L);
+  elbo_body(d, P, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, have_g ? &G : nullptr, b, t, L);
 }
 
 __global__ __launch_bounds__(256) void k_mix_fwd(const float *alpha, const float *base, float *out, int64_t total,
@@ -204,8 +205,8 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
 }
 
 int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth, const float *eps,
-                    float *terms, int32_t *chol_levels, float *g_mus, float *g_Sigmas, const kvae_lgssm_input_grads *g,
-                    void *stream) {
+                    float *terms, int32_t *chol_levels, float *ws_lz, float *g_mus, float *g_Sigmas,
+                    const kvae_lgssm_input_grads *g, void *stream) {
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!mus_smooth || !Sigmas_smooth || !eps || !terms || !chol_levels) return KVAE_ERR_NULL;
@@ -214,13 +215,13 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(chol_levels, 0, 2 * sizeof(int32_t), s) != hipSuccess) return launch_status("memset chol_levels");
   const unsigned grid = (unsigned)((int64_t)prob->B * prob->T);
-  KVAE_DISPATCH(*prob, k_elbo_probe<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, Sigmas_smooth, chol_levels));
+  KVAE_DISPATCH(*prob, k_elbo_probe<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, Sigmas_smooth, mus_smooth, eps, ws_lz, chol_levels));
   rc = launch_status("k_elbo_probe");
   if (rc) return rc;
   kvae_lgssm_input_grads gz;
   memset(&gz, 0, sizeof(gz));
   KVAE_DISPATCH(*prob, k_elbo<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps,
-                                           terms, (const int32_t *)chol_levels, g_mus, g_Sigmas, want_g ? *g : gz,
+                                           terms, (const int32_t *)chol_levels, (const float *)ws_lz, g_mus, g_Sigmas, want_g ? *g : gz,
                                            want_g ? 1 : 0));
   return launch_status("k_elbo");
 }
@@ -254,7 +255,7 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
 
 int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
 const char *kvae_last_error(void) { return g_err; }
-const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "2"; }
+const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "3"; }
 
 }  // extern "C"
 

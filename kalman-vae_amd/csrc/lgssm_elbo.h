@@ -74,11 +74,28 @@ KV_DEV void atomic_max_i32(int32_t *p, int32_t v) { if (v > *p) *p = v; }
 KV_DEV void atomic_max_i32(int32_t *p, int32_t v) { atomicMax(p, v); }
 #endif
 
+// ws (optional) receives per (b,t) the level-0 factor L_t (n*n) and the sample z_t = mu_t + L_t eps_t (n): when the
+// whole batch resolves to level 0 — the normal case — the main kernel reads them instead of re-factorising the
+// two neighbouring steps (3x fewer Cholesky factorisations and no re-reads of Sigma_s[t-1], Sigma_s[t+1]).
 template <class D>
-KV_DEV void elbo_probe_body(const D d, const kvae_lgssm_problem &P, const float *Sig_s, int32_t *levels,
-                            int b, int t, ElboLds<D> &L) {
+KV_DEV void elbo_probe_body(const D d, const kvae_lgssm_problem &P, const float *Sig_s, const float *mus,
+                            const float *eps, float *ws, int32_t *levels, int b, int t, ElboLds<D> &L) {
   const int n = d.n(), nn = n * n;
-  const int ls = probe_level(L.Ls, L.sym, Sig_s + ((int64_t)b * P.T + t) * nn, n);
+  const int64_t q0 = (int64_t)b * P.T + t;
+  const int ls = probe_level(L.Ls, L.sym, Sig_s + q0 * nn, n);
+  if (ws && ls == 0) {
+    copy_in(L.eps, eps + q0 * n, n);
+    copy_in(L.mu, mus + q0 * n, n);
+    KV_SYNC();
+    float *w = ws + q0 * (nn + n);
+    KV_PAR(e, nn) { w[e] = L.Ls[e]; }
+    KV_PAR(i, n) {
+      float acc = L.mu[i];
+      for (int k = 0; k <= i; ++k) acc = fmaf(L.Ls[i * n + k], L.eps[k], acc);
+      w[nn + i] = acc;
+    }
+    KV_SYNC();
+  }
   int lq = 0;
   const bool q_shared = (P.Q.sb == 0 && P.Q.st == 0);
   if (t >= 1 && (!q_shared || (b == 0 && t == 1))) lq = probe_level(L.LQ, L.sym, stack_at(P.Q, b, t), n);
@@ -115,8 +132,8 @@ KV_DEV float log_diag_sum(const float *Lm, int n) {
 
 template <class D>
 KV_DEV void elbo_body(const D d, const kvae_lgssm_problem &P, const float *mus, const float *Sigs,
-                      const float *eps, float *terms, const int32_t *levels, float *g_mus, float *g_Sigs,
-                      const kvae_lgssm_input_grads *Gp, int b, int t, ElboLds<D> &L) {
+                      const float *eps, float *terms, const int32_t *levels, const float *ws, float *g_mus,
+                      float *g_Sigs, const kvae_lgssm_input_grads *Gp, int b, int t, ElboLds<D> &L) {
   const int n = d.n(), m = d.m(), p = d.p(), T = P.T, nn = n * n;
   const int64_t bT = (int64_t)b * T, q = bT + t;
   const int lvS = levels[0], lvQ = levels[1];
@@ -124,7 +141,16 @@ KV_DEV void elbo_body(const D d, const kvae_lgssm_problem &P, const float *mus, 
   const bool has_prev = t >= 1, has_next = t + 1 < T;
 
   // ---- z_{t-1}, z_t, z_{t+1} = mu_s + chol(Sigma_s) eps  (kalman_filter.py:348-351) ----------
-  for (int dt = -1; dt <= 1; ++dt) {
+  const bool stashed = (ws != nullptr) && lvS == 0;   // the probe launch already factorised every step at level 0
+  if (stashed) {
+    copy_in(L.Ls, ws + q * (nn + n), nn);
+    for (int dt = -1; dt <= 1; ++dt) {
+      const int tt = t + dt;
+      if (tt >= 0 && tt < T) copy_in(L.z[dt + 1], ws + (bT + tt) * (nn + n) + nn, n);
+    }
+    KV_SYNC();
+  }
+  for (int dt = -1; dt <= 1 && !stashed; ++dt) {
     const int tt = t + dt;
     if (tt < 0 || tt >= T) continue;
     float *Lo = (dt == 0) ? L.Ls : L.Xb;  // only L_t is kept

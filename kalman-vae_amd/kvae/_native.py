@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -68,7 +68,7 @@ class LgssmLib:
             getattr(d, name).restype = C.c_int
         d.kvae_lgssm_smooth_bwd.argtypes = [P, S, S, G, vp, C.c_int, vp]
         d.kvae_lgssm_smooth_bwd.restype = C.c_int
-        d.kvae_lgssm_elbo.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, G, vp]
+        d.kvae_lgssm_elbo.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, G, vp]
         d.kvae_lgssm_elbo.restype = C.c_int
         d.kvae_mix_fwd.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_mix_fwd.restype = C.c_int

@@ -203,6 +203,7 @@ class LgssmElbo(torch.autograd.Function):
         Sigs_c, eps_c = _f32c(Sigs), _f32c(eps)
         terms = torch.empty(Bsz, T, 4, device=dev, dtype=torch.float32)
         levels = torch.empty(2, device=dev, dtype=torch.int32)
+        ws_lz = torch.empty(Bsz, T, n * n + n, device=dev, dtype=torch.float32)
         want = any(ctx.needs_input_grad)
         g_mus = g_Sigs = sink = None
         if want:
@@ -211,7 +212,7 @@ class LgssmElbo(torch.autograd.Function):
             g_mus, g_Sigs = torch.empty_like(mus_c), torch.empty_like(Sigs_c)
             ctx.need_q = need_q
         call.lib.check(N.timed("elbo", call.Y, lambda: call.lib.dll.kvae_lgssm_elbo(
-            C.byref(call.prob), N.ptr(mus_c), N.ptr(Sigs_c), N.ptr(eps_c), N.ptr(terms), N.ptr(levels), N.ptr(g_mus),
+            C.byref(call.prob), N.ptr(mus_c), N.ptr(Sigs_c), N.ptr(eps_c), N.ptr(terms), N.ptr(levels), N.ptr(ws_lz), N.ptr(g_mus),
             N.ptr(g_Sigs), C.byref(sink.g) if sink else None, call.stream)), "kvae_lgssm_elbo")
         per_term = terms.sum((0, 1))
         ctx.sink, ctx.g_mus, ctx.g_Sigs, ctx.mus_shape = sink, g_mus, g_Sigs, mus.shape

@@ -98,19 +98,19 @@ static void run_bwd(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, con
 
 template <class D>
 static void run_elbo(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps, float *terms,
-                     int32_t *levels, float *g_mus, float *g_Sigs, const kvae_lgssm_input_grads *g) {
+                     int32_t *levels, float *ws, float *g_mus, float *g_Sigs, const kvae_lgssm_input_grads *g) {
   auto L = std::make_unique<ElboLds<D>>();
   const D d(P.n, P.m, P.p);
   levels[0] = levels[1] = 0;
   for (int b = 0; b < P.B; ++b)
     for (int t = 0; t < P.T; ++t) {
       memset(L.get(), 0xFF, sizeof(*L));
-      elbo_probe_body(d, P, Sigs, levels, b, t, *L);
+      elbo_probe_body(d, P, Sigs, mus, eps, ws, levels, b, t, *L);
     }
   for (int b = 0; b < P.B; ++b)
     for (int t = 0; t < P.T; ++t) {
       memset(L.get(), 0xFF, sizeof(*L));
-      elbo_body(d, P, mus, Sigs, eps, terms, levels, g_mus, g_Sigs, g, b, t, *L);
+      elbo_body(d, P, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, g, b, t, *L);
     }
 }
 
@@ -147,13 +147,13 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
 }
 
 int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth, const float *eps,
-                    float *terms, int32_t *chol_levels, float *g_mus, float *g_Sigmas, const kvae_lgssm_input_grads *g,
-                    void *) {
+                    float *terms, int32_t *chol_levels, float *ws_lz, float *g_mus, float *g_Sigmas,
+                    const kvae_lgssm_input_grads *g, void *) {
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!mus_smooth || !Sigmas_smooth || !eps || !terms || !chol_levels) return KVAE_ERR_NULL;
   if (g_mus && (!g_Sigmas || !g || !g->gA.ptr || !g->gB.ptr || !g->gC.ptr || !g->gY)) return KVAE_ERR_NULL;
-  KVAE_DISPATCH(*prob, (run_elbo<D>(*prob, mus_smooth, Sigmas_smooth, eps, terms, chol_levels, g_mus, g_Sigmas, g)));
+  KVAE_DISPATCH(*prob, (run_elbo<D>(*prob, mus_smooth, Sigmas_smooth, eps, terms, chol_levels, ws_lz, g_mus, g_Sigmas, g)));
   return KVAE_OK;
 }
 
