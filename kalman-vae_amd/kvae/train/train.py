@@ -40,6 +40,9 @@ class Trainer:
             off += p.numel()
         on_gpu = dev.type == "cuda"
         self.opt = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
+        # beta of the KL term lives in a device scalar so that the schedule can move without re-capturing the graph
+        self.beta_t = torch.tensor(float(model.beta), device=dev, dtype=torch.float32)
+        model.beta = self.beta_t
         self.use_graph = bool(use_graph) and on_gpu
         # the LGSSM chain runs on its own stream next to the decoder convolutions (fork/join inside the graph)
         model.lgssm_stream = torch.cuda.Stream() if (on_gpu and overlap_lgssm and self.use_graph) else None
@@ -68,6 +71,10 @@ class Trainer:
             self.flat_grad.mul_(torch.clamp(self.clip / (total + 1e-6), max=1.0))
             self.out["grad_norm"] = total
         self.opt.step()
+
+    def set_beta(self, value: float):
+        """Linear KL warm-up (reference train.py:30): updates the device scalar the captured graph reads."""
+        self.beta_t.fill_(float(value))
 
     # -- public ---------------------------------------------------------------------------------------
     def step(self, x):
@@ -137,7 +144,7 @@ def train_one_epoch(trainer, loader, device, epoch=None):
     model = trainer.model
     model.train()
     if model.config.scheduled_beta and epoch is not None:
-        model.beta = model.scheduler.get_beta(epoch)
+        trainer.set_beta(model.scheduler.get_beta(epoch))
     sums, n = None, 0
     for batch in loader:
         x = batch["images"].float().to(device, non_blocking=True)

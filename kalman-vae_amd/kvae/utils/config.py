@@ -88,3 +88,36 @@ class KVAEConfig:
         if not 1 <= self.num_modes <= 16:
             raise ValueError("num_modes must be in 1..16")
         return self
+
+    # -- convenience (not in the reference) --------------------------------------------------------------------
+    def to_dict(self) -> dict:
+        return {f.name: getattr(self, f.name) for f in fields(self)}
+
+    @classmethod
+    def from_yaml(cls, path, section: str = "kvae") -> "KVAEConfig":
+        """Read the `kvae:` section of a reference-style YAML config (kvae/train/config.yaml there)."""
+        import yaml
+        with open(path) as fh:
+            doc = yaml.safe_load(fh) or {}
+        return cls.from_dict(doc.get(section, doc) or {})
+
+    def lgssm_dims(self):
+        """(n, m, p) = (dim z, dim u, dim a) as the HIP kernels name them."""
+        return self.z_dim, self.u_dim, self.a_dim
+
+    def fast_path(self) -> dict:
+        """Which hand-specialised kernels this configuration hits (everything else runs the generic instantiations)."""
+        n, m, p = self.lgssm_dims()
+        return {
+            "lgssm_n4_fused": (n, m, p) == (4, 4, 2),
+            "lgssm_static_16": (n, m, p) == (16, 16, 2),
+            "lstm_registers": self.dynamics_model.lower() == "lstm" and (self.dynamics_hidden_dim, p) == (50, 2),
+            "bigru_registers": self.dynamics_model.lower() == "switching" and (self.dynamics_hidden_dim, p) == (50, 2),
+            "regime_chain": self.dynamics_model.lower() == "switching" and self.num_modes <= 16,
+        }
+
+    def describe(self) -> str:
+        n, m, p = self.lgssm_dims()
+        fp = ", ".join(k for k, v in self.fast_path().items() if v) or "generic kernels"
+        return (f"KVAE[{self.dynamics_model}] K={self.num_modes} z={n} u={m} a={p} "
+                f"frames {self.img_channels}x{self.img_size}x{self.img_size} out={self.out_distr} | {fp}")
