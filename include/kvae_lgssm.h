@@ -198,6 +198,14 @@ int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in,
                               int32_t C, int32_t H, int32_t W, int32_t r, int32_t relu, void *stream);
 int64_t kvae_bias_partial_rows(int64_t N);
 
+/* ---- fused Bernoulli reconstruction term of the frame VAE --------------------------------- */
+
+/* frame_ll[f] = -sum_{pixels} BCEWithLogits(logits[f,:], x[f,:]) for f < frames (kvae/vae/losses.py:85-87). */
+int kvae_bce_frames_fwd(const float *logits, const float *x, float *frame_ll, int64_t frames, int32_t pixels, void *stream);
+/* g_logits[f,:] = -g_frame[f] * (sigmoid(logits[f,:]) - x[f,:]). */
+int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_frame, float *g_logits, int64_t frames,
+                        int32_t pixels, void *stream);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

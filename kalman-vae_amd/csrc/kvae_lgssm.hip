@@ -504,3 +504,64 @@ int kvae_bigru_bwd(const float *g_h, const float *gates, const float *h_seq, con
   return launch_status("k_gru_bwd_fast");
 }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// fused Bernoulli reconstruction term (vae_loss.h): one wavefront per frame
+// ---------------------------------------------------------------------------------------------
+#include "vae_loss.h"
+
+__global__ __launch_bounds__(256) void k_vae_bce_fwd(const float *__restrict__ logits, const float *__restrict__ x,
+                                                     float *__restrict__ frame_ll, int64_t frames, int pixels) {
+  const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (f >= frames) return;
+  const float *l = logits + f * pixels, *t = x + f * pixels;
+  float acc = 0.f;
+  if ((pixels & 3) == 0 && (((uintptr_t)l | (uintptr_t)t) & 15) == 0) {
+    for (int i = lane * 4; i < pixels; i += 256) {
+      const float4 a = *reinterpret_cast<const float4 *>(l + i), b = *reinterpret_cast<const float4 *>(t + i);
+      acc += bce_logit(a.x, b.x) + bce_logit(a.y, b.y) + bce_logit(a.z, b.z) + bce_logit(a.w, b.w);
+    }
+  } else {
+    for (int i = lane; i < pixels; i += 64) acc += bce_logit(l[i], t[i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) frame_ll[f] = -acc;
+}
+
+__global__ __launch_bounds__(256) void k_vae_bce_bwd(const float *__restrict__ logits, const float *__restrict__ x,
+                                                     const float *__restrict__ g_frame, float *__restrict__ g_logits,
+                                                     int64_t total, int pixels) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+    const float g = -g_frame[i / pixels];   // pixels % 4 == 0 on this path: the 4 elements share a frame
+    const float4 a = *reinterpret_cast<const float4 *>(logits + i), b = *reinterpret_cast<const float4 *>(x + i);
+    *reinterpret_cast<float4 *>(g_logits + i) = make_float4(g * (sigmoid_stable(a.x) - b.x), g * (sigmoid_stable(a.y) - b.y),
+                                                            g * (sigmoid_stable(a.z) - b.z), g * (sigmoid_stable(a.w) - b.w));
+  }
+}
+__global__ __launch_bounds__(256) void k_vae_bce_bwd_scalar(const float *logits, const float *x, const float *g_frame,
+                                                            float *g_logits, int64_t total, int pixels) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    g_logits[i] = -g_frame[i / pixels] * (sigmoid_stable(logits[i]) - x[i]);
+}
+
+extern "C" {
+int kvae_bce_frames_fwd(const float *logits, const float *x, float *frame_ll, int64_t frames, int32_t pixels, void *stream) {
+  if (!logits || !x || !frame_ll) return KVAE_ERR_NULL;
+  if (frames < 1 || pixels < 1) return KVAE_ERR_ARG;
+  k_vae_bce_fwd<<<dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(logits, x, frame_ll, frames, pixels);
+  return launch_status("k_vae_bce_fwd");
+}
+int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_frame, float *g_logits, int64_t frames,
+                        int32_t pixels, void *stream) {
+  if (!logits || !x || !g_frame || !g_logits) return KVAE_ERR_NULL;
+  if (frames < 1 || pixels < 1) return KVAE_ERR_ARG;
+  const int64_t total = frames * pixels;
+  const bool v4 = (pixels & 3) == 0 && ((((uintptr_t)logits | (uintptr_t)x | (uintptr_t)g_logits) & 15) == 0);
+  if (v4)
+    k_vae_bce_bwd<<<dim3(epi_grid(total / 4)), dim3(256), 0, (hipStream_t)stream>>>(logits, x, g_frame, g_logits, total, pixels);
+  else
+    k_vae_bce_bwd_scalar<<<dim3(epi_grid(total)), dim3(256), 0, (hipStream_t)stream>>>(logits, x, g_frame, g_logits, total, pixels);
+  return launch_status("k_vae_bce_bwd");
+}
+}  // extern "C"

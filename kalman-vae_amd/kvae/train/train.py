@@ -46,6 +46,9 @@ class Trainer:
         self.use_graph = bool(use_graph) and on_gpu
         # the LGSSM chain runs on its own stream next to the decoder convolutions (fork/join inside the graph)
         model.lgssm_stream = torch.cuda.Stream() if (on_gpu and overlap_lgssm and self.use_graph) else None
+        if model.lgssm_stream is not None and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            # gradients of the LGSSM parameters are produced on the side stream by design
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.graph_fb = self.graph_opt = None
         self.static_x = None
         self.out = {}

@@ -42,3 +42,31 @@ def conv_block(x, conv, r=1, relu=True):
     """conv (MIOpen, no bias) -> fused bias + PixelShuffle(r) + optional ReLU."""
     y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     return BiasShuffleAct.apply(y, conv.bias, r, relu)
+
+
+class BernoulliFrameLogLik(torch.autograd.Function):
+    """[B,T] log p(x_t | a_t) = -sum_pixels BCEWithLogits(x_logits, x) (reference kvae/vae/losses.py:85-87) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x_logits, x):
+        lg, xx = x_logits.contiguous(), x.contiguous()
+        lead = lg.shape[:2]
+        frames = lead[0] * lead[1]
+        pixels = lg.numel() // frames
+        out = torch.empty(lead, device=lg.device, dtype=torch.float32)
+        lib = N.lib_for(lg)
+        lib.check(lib.dll.kvae_bce_frames_fwd(N.ptr(lg), N.ptr(xx), N.ptr(out), frames, pixels, N.stream_for(lg)),
+                  "kvae_bce_frames_fwd")
+        ctx.save_for_backward(lg, xx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, xx = ctx.saved_tensors
+        g = g.contiguous()
+        frames = g.numel()
+        g_logits = torch.empty_like(lg)
+        lib = N.lib_for(lg)
+        lib.check(lib.dll.kvae_bce_frames_bwd(N.ptr(lg), N.ptr(xx), N.ptr(g), N.ptr(g_logits), frames, lg.numel() // frames,
+                                              N.stream_for(lg)), "kvae_bce_frames_bwd")
+        return g_logits, None

@@ -37,7 +37,12 @@ def vae_loss(x, x_mu, x_var, a, a_mu, a_var, scale_reconstruction: float = 0.3, 
     mk = _frame_mask(mask, x)
     denom = mk.sum().clamp(min=1.0)
     if out_distr.lower() == "bernoulli":
-        lpx = -F.binary_cross_entropy_with_logits(x_mu, x, reduction="none").sum(dim=(2, 3, 4))
+        from kvae import _native
+        if _native.fused_ok(x_mu) and x_mu.dtype == torch.float32 and x.dtype == torch.float32 and not x.requires_grad:
+            from kvae.vae.fused import BernoulliFrameLogLik
+            lpx = BernoulliFrameLogLik.apply(x_mu, x)    # one HIP pass per direction (csrc/vae_loss.h)
+        else:
+            lpx = -F.binary_cross_entropy_with_logits(x_mu, x, reduction="none").sum(dim=(2, 3, 4))
         log_px = (lpx * mk).sum()
         log_qa = (log_gaussian(a, a_mu, a_var).sum(-1) * mk).sum()
     else:

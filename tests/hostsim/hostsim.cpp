@@ -271,3 +271,24 @@ int kvae_bigru_fwd(const float *, const float *const *, const float *const *, co
 int kvae_bigru_bwd(const float *, const float *, const float *, const float *const *, const float *const *, float *, float *,
                    float *, int32_t, int32_t, int32_t, int32_t, void *) { return KVAE_ERR_DIMS; }
 }
+
+#include "../../kalman-vae_amd/csrc/vae_loss.h"
+extern "C" {
+int kvae_bce_frames_fwd(const float *logits, const float *x, float *frame_ll, int64_t frames, int32_t pixels, void *) {
+  if (!logits || !x || !frame_ll) return KVAE_ERR_NULL;
+  if (frames < 1 || pixels < 1) return KVAE_ERR_ARG;
+  for (int64_t f = 0; f < frames; ++f) {
+    float acc = 0.f;
+    for (int i = 0; i < pixels; ++i) acc += bce_logit(logits[f * pixels + i], x[f * pixels + i]);
+    frame_ll[f] = -acc;
+  }
+  return KVAE_OK;
+}
+int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_frame, float *g_logits, int64_t frames,
+                        int32_t pixels, void *) {
+  if (!logits || !x || !g_frame || !g_logits) return KVAE_ERR_NULL;
+  if (frames < 1 || pixels < 1) return KVAE_ERR_ARG;
+  for (int64_t i = 0; i < frames * pixels; ++i) g_logits[i] = -g_frame[i / pixels] * (sigmoid_stable(logits[i]) - x[i]);
+  return KVAE_OK;
+}
+}

@@ -173,3 +173,20 @@ def regime_vs_torch(DEV, B, T, K, tau, hard):
     ref_lg = lr.grad if lr.grad is not None else torch.zeros_like(logits)   # T == 1: transition logits unused
     assert (ld.grad.cpu() - ref_lg).abs().max() <= 2e-4 * ref_lg.abs().max() + 1e-12
     assert rel_err(idv.grad.cpu(), ir.grad) < 2e-4
+
+
+def bce_frames_vs_torch(DEV, B, T, C, H, W):
+    import torch.nn.functional as F
+    from kvae.vae.fused import BernoulliFrameLogLik
+    g = torch.Generator().manual_seed(B + T + H)
+    logits = 3 * torch.randn(B, T, C, H, W, generator=g)
+    x = (torch.rand(B, T, C, H, W, generator=g) < 0.2).float()
+    w = torch.randn(B, T, generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = -F.binary_cross_entropy_with_logits(lr, x, reduction="none").sum(dim=(2, 3, 4))
+    (ref * w).sum().backward()
+    ld = logits.clone().to(DEV).requires_grad_(True)
+    out = BernoulliFrameLogLik.apply(ld, x.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(ld.grad.cpu(), lr.grad) < 1e-5

@@ -185,3 +185,8 @@ def test_bigru_gpu(B, T):
     assert rel_err(xd.grad.cpu(), xr.grad) < 2e-4
     for n, got in zip(names, params):
         assert rel_err(got.grad.cpu(), getattr(ref, n).grad) < 2e-4, n
+
+
+@pytest.mark.parametrize("shape", [(256, 50, 1, 32, 32), (2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
+def test_bce_frames_gpu(shape):
+    parity_cases.bce_frames_vs_torch(DEV, *shape)

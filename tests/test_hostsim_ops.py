@@ -165,3 +165,9 @@ def test_vae_fused_matches_unfused_hostsim():
 def test_regime_hostsim(B, T, K, tau, hard):
     import parity_cases
     parity_cases.regime_vs_torch("cpu", B, T, K, tau, hard)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
+def test_bce_frames_hostsim(shape):
+    import parity_cases
+    parity_cases.bce_frames_vs_torch("cpu", *shape)
