@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "lgssm_bwd.h"
@@ -158,6 +159,12 @@ static int check_problem(const kvae_lgssm_problem *p) {
     }                                                            \
   } while (0)
 
+// kvae_lgssm_wide.hip: the same bodies with 256 threads per sequence (used when n > 8)
+extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
+                                     hipStream_t s);
+extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                                     const kvae_lgssm_input_grads *out, float *ws, int with_rts, hipStream_t s);
+
 static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int do_filter, int do_rts,
                       void *stream) {
   int rc = check_problem(prob);
@@ -169,6 +176,10 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
     // rts-only calls need no gains; filter calls use the fused-phase kernel when the caller provides aux
     k_smooth_fwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts);
     return launch_status("k_smooth_fwd_n4");
+  }
+  if (prob->n > 8) {
+    kvae_wide_launch_fwd(prob, st, do_filter, do_rts, s);
+    return launch_status("k_smooth_fwd_wide");
   }
   KVAE_DISPATCH(*prob, k_smooth_fwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts));
   return launch_status("k_smooth_fwd");
@@ -198,6 +209,10 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {
     k_smooth_bwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws, with_rts);
     return launch_status("k_smooth_bwd_n4");
+  }
+  if (prob->n > 8 && getenv("KVAE_WIDE_BWD")) {   // measured slower than one wavefront at n = 16 (17.9 vs 15.6 ms at the C5
+    kvae_wide_launch_bwd(prob, saved, up, out, ws, with_rts, s);   // shard): the backward is bound by its serial solves; opt-in only
+    return launch_status("k_smooth_bwd_wide");
   }
   KVAE_DISPATCH(*prob, k_smooth_bwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws,
                                            with_rts));

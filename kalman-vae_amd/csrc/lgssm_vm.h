@@ -35,7 +35,9 @@
 #include <hip/hip_runtime.h>
 #define KV_DEV __device__ __forceinline__
 #define KV_MEM __device__ __forceinline__
-#define KV_LANES 64
+#ifndef KV_LANES
+#define KV_LANES 64   // threads per problem: 64 = one wavefront; kvae_lgssm_wide.hip builds the bodies with 256
+#endif
 #define KV_LANE ((int)threadIdx.x)
 #define KV_SYNC() __syncthreads()
 #define KV_UNROLL _Pragma("unroll")
