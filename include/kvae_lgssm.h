@@ -99,6 +99,15 @@ int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *
  * replaces KalmanFilter.smooth (kalman_filter.py:240-279). Writes all six stacks. */
 int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream);
 
+/* Kalman filter with the LSTM alpha-network stepped INSIDE the kernel (masked sequences: the network input of a
+ * hidden step is C_t mu_{t|t-1}, kalman_filter.py:183-185; dyn_param.py:39-63).  prob->A/Bm/C are ignored: the step
+ * matrices are mixed from the K mode matrices A[K,n,n], Bm[K,n,m], C[K,p,n] and ALSO written to record [B,T,n*n+n*m+p*n]
+ * (A|B|C per step) and alpha [B,T,K].  Forward only.  Limits: H == 50, p == 2, K <= 16 (else KVAE_ERR_DIMS). */
+int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, const float *w_ih,
+                                 const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
+                                 const float *head_b, const float *A, const float *Bm, const float *C, int32_t K, int32_t H,
+                                 float *record, float *alpha, void *stream);
+
 /* ---- backward ----------------------------------------------------------------------------- */
 
 /* Reverse-mode of kvae_lgssm_smooth_fwd (with_rts = 1) or kvae_lgssm_filter_fwd (with_rts = 0):

@@ -165,6 +165,11 @@ extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgs
 extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                                      const kvae_lgssm_input_grads *out, float *ws, int with_rts, hipStream_t s);
 
+extern "C" int kvae_wide_launch_filter_alpha_lstm(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, const float *w_ih,
+                                                  const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
+                                                  const float *head_b, const float *A, const float *Bm, const float *C, int K,
+                                                  int H, float *record, float *alpha, hipStream_t s);
+
 static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int do_filter, int do_rts,
                       void *stream) {
   int rc = check_problem(prob);
@@ -195,6 +200,22 @@ int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *
 }
 int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream) {
   return launch_fwd(prob, out, 1, 1, stream);
+}
+
+int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, const float *w_ih,
+                                 const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
+                                 const float *head_b, const float *A, const float *Bm, const float *C, int32_t K, int32_t H,
+                                 float *record, float *alpha, void *stream) {
+  if (!prob || !out) return KVAE_ERR_NULL;
+  if (prob->B < 1 || prob->T < 1 || prob->n < 1 || prob->m < 1 || prob->n > KVAE_MAX_DIM || prob->m > KVAE_MAX_DIM)
+    return KVAE_ERR_DIMS;
+  if (!prob->Q.ptr || !prob->R || !prob->mu0 || !prob->Sigma0 || !prob->Y || !prob->U || !w_ih || !w_hh || !b_ih || !b_hh ||
+      !head_w || !head_b || !A || !Bm || !C || !record || !alpha || !out->mus_filt || !out->Sigmas_filt || !out->mus_pred ||
+      !out->Sigmas_pred)
+    return KVAE_ERR_NULL;
+  const int rc = kvae_wide_launch_filter_alpha_lstm(prob, out, w_ih, w_hh, b_ih, b_hh, head_w, head_b, A, Bm, C, K, H, record,
+                                                    alpha, (hipStream_t)stream);
+  return rc ? rc : launch_status("k_filter_alpha_lstm");
 }
 
 int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,

@@ -152,6 +152,68 @@ KV_DEV void filter_gain(const D d, LDS &L, bool predict, float *Ssave) {
   lu_solve(L.aug, p, n, L.Kt, n);  // Kt[p,n]
 }
 
+// One predict + update on the operands and belief held in LDS (the body of the filter loop, shared with the
+// masked alpha-network kernel in kvae_lgssm_wide.hip): writes pred/filt outputs of step bt and carries (mu, Sig).
+template <class D, class LDS>
+KV_DEV void filter_step_core(const D d, const kvae_lgssm_states &S, int64_t bt, LDS &L) {
+  const int n = d.n(), p = d.p(), nn = n * n;
+  filter_gain(d, L, true, nullptr);
+  const float mk = L.mk[0];
+  // predicted belief is final here: stream it out
+  copy_out(S.mus_pred + bt * n, L.mup, n);
+  copy_out(S.Sigmas_pred + bt * nn, L.Sigp, nn);
+  // phase: K = mask * Kt^T ; IKC = I - K C ; KR = K R ; mu_f = mup + K r
+  KV_PAR(e, nn) {
+    const int i = e / n, j = e - i * n;
+    float acc = 0.f;
+    for (int k = 0; k < p; ++k) acc = fmaf(mk * L.Kt[k * n + i], L.C[k * n + j], acc);
+    L.IKC[e] = (i == j ? 1.0f : 0.0f) - acc;
+  }
+  KV_PAR(e, n * p) {
+    const int i = e / p, j = e - i * p;
+    float acc = 0.f;
+    for (int k = 0; k < p; ++k) acc = fmaf(mk * L.Kt[k * n + i], L.R[k * p + j], acc);
+    L.KR[e] = acc;
+  }
+  KV_PAR(i, n) {
+    float acc = L.mup[i];
+    for (int k = 0; k < p; ++k) acc = fmaf(mk * L.Kt[k * n + i], L.r[k], acc);
+    L.muf[i] = acc;
+  }
+  KV_SYNC();
+  // phase: T1 = IKC Sigp
+  KV_PAR(e, nn) {
+    const int i = e / n, j = e - i * n;
+    float acc = 0.f;
+    for (int k = 0; k < n; ++k) acc = fmaf(L.IKC[i * n + k], L.Sigp[k * n + j], acc);
+    L.T1[e] = acc;
+  }
+  KV_SYNC();
+  // phase: F0 = T1 IKC^T + KR K^T (Joseph form)
+  KV_PAR(e, nn) {
+    const int i = e / n, j = e - i * n;
+    float acc = 0.f;
+    for (int k = 0; k < n; ++k) acc = fmaf(L.T1[i * n + k], L.IKC[j * n + k], acc);
+    float acc2 = 0.f;
+    for (int k = 0; k < p; ++k) acc2 = fmaf(L.KR[i * p + k], mk * L.Kt[k * n + j], acc2);
+    L.F0[e] = acc + acc2;
+  }
+  KV_SYNC();
+  // phase: Sig_f = sym(F0); carry (mu_f, Sig_f) to the next step and stream them out
+  KV_PAR(e, nn) {
+    const int i = e / n, j = e - i * n;
+    const float v = 0.5f * (L.F0[e] + L.F0[j * n + i]);
+    L.Sig[e] = v;
+    S.Sigmas_filt[bt * nn + e] = v;
+  }
+  KV_PAR(i, n) {
+    const float v = L.muf[i];
+    L.mu[i] = v;
+    S.mus_filt[bt * n + i] = v;
+  }
+  KV_SYNC();
+}
+
 template <class D>
 KV_DEV void filter_sweep(const D d, const kvae_lgssm_problem &P, const kvae_lgssm_states &S, int b, FwdLds<D> &L) {
   const int n = d.n(), m = d.m(), p = d.p(), T = P.T, nn = n * n;
@@ -170,62 +232,7 @@ KV_DEV void filter_sweep(const D d, const kvae_lgssm_problem &P, const kvae_lgss
       operands_load(d, P, b, t, L);
     }
     KV_SYNC();
-    filter_gain(d, L, true, nullptr);
-    const float mk = L.mk[0];
-    const int64_t bt = (int64_t)b * T + t;
-    // predicted belief is final here: stream it out
-    copy_out(S.mus_pred + bt * n, L.mup, n);
-    copy_out(S.Sigmas_pred + bt * nn, L.Sigp, nn);
-    // phase: K = mask * Kt^T ; IKC = I - K C ; KR = K R ; mu_f = mup + K r
-    KV_PAR(e, nn) {
-      const int i = e / n, j = e - i * n;
-      float acc = 0.f;
-      for (int k = 0; k < p; ++k) acc = fmaf(mk * L.Kt[k * n + i], L.C[k * n + j], acc);
-      L.IKC[e] = (i == j ? 1.0f : 0.0f) - acc;
-    }
-    KV_PAR(e, n * p) {
-      const int i = e / p, j = e - i * p;
-      float acc = 0.f;
-      for (int k = 0; k < p; ++k) acc = fmaf(mk * L.Kt[k * n + i], L.R[k * p + j], acc);
-      L.KR[e] = acc;
-    }
-    KV_PAR(i, n) {
-      float acc = L.mup[i];
-      for (int k = 0; k < p; ++k) acc = fmaf(mk * L.Kt[k * n + i], L.r[k], acc);
-      L.muf[i] = acc;
-    }
-    KV_SYNC();
-    // phase: T1 = IKC Sigp
-    KV_PAR(e, nn) {
-      const int i = e / n, j = e - i * n;
-      float acc = 0.f;
-      for (int k = 0; k < n; ++k) acc = fmaf(L.IKC[i * n + k], L.Sigp[k * n + j], acc);
-      L.T1[e] = acc;
-    }
-    KV_SYNC();
-    // phase: F0 = T1 IKC^T + KR K^T (Joseph form)
-    KV_PAR(e, nn) {
-      const int i = e / n, j = e - i * n;
-      float acc = 0.f;
-      for (int k = 0; k < n; ++k) acc = fmaf(L.T1[i * n + k], L.IKC[j * n + k], acc);
-      float acc2 = 0.f;
-      for (int k = 0; k < p; ++k) acc2 = fmaf(L.KR[i * p + k], mk * L.Kt[k * n + j], acc2);
-      L.F0[e] = acc + acc2;
-    }
-    KV_SYNC();
-    // phase: Sig_f = sym(F0); carry (mu_f, Sig_f) to the next step and stream them out
-    KV_PAR(e, nn) {
-      const int i = e / n, j = e - i * n;
-      const float v = 0.5f * (L.F0[e] + L.F0[j * n + i]);
-      L.Sig[e] = v;
-      S.Sigmas_filt[bt * nn + e] = v;
-    }
-    KV_PAR(i, n) {
-      const float v = L.muf[i];
-      L.mu[i] = v;
-      S.mus_filt[bt * n + i] = v;
-    }
-    KV_SYNC();
+    filter_step_core(d, S, (int64_t)b * T + t, L);
   }
 }
 

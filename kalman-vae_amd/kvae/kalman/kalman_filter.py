@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import noise
+from . import lgssm_ops
 from .lgssm_ops import LgssmElbo, LgssmSmooth, Slots
 
 _NO_SLOTS = Slots()
@@ -125,7 +126,26 @@ class KalmanFilter(nn.Module):
             _native.lib_for(Y)  # raises: no CPU fallback (unless a test injected the host simulator)
         mask = self._mask(mask, Y)
         ops = self._operands(Y, mask)
-        if ops is None:  # lstm + missing frames
+        if ops is None and Y.is_cuda and not (torch.is_grad_enabled() and (Y.requires_grad or any(
+                q.requires_grad for q in self.dyn_params.parameters()))):
+            # lstm + missing frames, no gradients wanted (imputation / evaluation): alpha-network inside the kernel
+            dyn = self.dyn_params
+            res = lgssm_ops.alpha_lstm_filter(Y, U, mask, dyn.lstm, dyn.head_w, dyn.A, dyn.B, dyn.C, self.Q, self.R,
+                                              self.mu0, self.Sigma0)
+            if res is not None:
+                mf, Sf, mp, Sp, rec, slots, alpha = res
+                n, m, p = self.n, self.m, self.p
+                views = (rec[..., :n * n].unflatten(-1, (n, n)), rec[..., n * n:n * n + n * m].unflatten(-1, (n, m)),
+                         rec[..., n * n + n * m:].unflatten(-1, (p, n)))
+                dyn.state_seq = alpha
+                self._last = dict(rec=rec, slots=slots, A=None, B=None, C=None, Q=self.Q, views=views, Q_view=None)
+                u1 = lambda v: v.unsqueeze(-1)
+                if not with_rts:
+                    return None, None, u1(mf), Sf, u1(mp), Sp
+                ms, Ss = lgssm_ops.rts_only(Y, U, mask, rec, None, None, None, self.Q, self.R, self.mu0, self.Sigma0, slots,
+                                            mf, Sf, mp, Sp)
+                return u1(ms), Ss, u1(mf), Sf, u1(mp), Sp
+        if ops is None:  # lstm + missing frames (training with masks, or shapes outside the fused kernel)
             mf, Sf, mp, Sp, A_l, B_l, C_l = self._filter_stepwise(Y, U, mask)
             self._last = dict(rec=None, slots=_NO_SLOTS, A=A_l, B=B_l, C=C_l, Q=self.Q, views=(A_l, B_l, C_l),
                               Q_view=None)

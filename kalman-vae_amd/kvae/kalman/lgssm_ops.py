@@ -401,3 +401,44 @@ class BiGruSequence(torch.autograd.Function):
             di, dh = dpi[d].reshape(Bsz * T, 3 * H), dph[d].reshape(Bsz * T, 3 * H)
             out += [di.t() @ x2, dh.t() @ hp[d].reshape(Bsz * T, H), di.sum(0), dh.sum(0)]
         return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# masked sequences with the LSTM alpha-network: filter with the network inside the kernel (no autograd)
+# ------------------------------------------------------------------------------------------------
+ALPHA_LSTM_SUPPORTED = dict(hidden=50, p=2, max_K=16)
+
+
+@torch.no_grad()
+def alpha_lstm_filter(Y, U, mask, lstm, head, A, Bm, Cm, Q, R, mu0, Sigma0):
+    """Kalman filter whose per-step alpha comes from an LSTM fed with C mu_{t|t-1} on hidden frames (reference
+    kalman_filter.py:151-185 + dyn_param.py:39-63) in ONE launch. Returns (mf, Sf, mp, Sp, record, slots, alpha)."""
+    Y, U, mask = _f32c(Y), _f32c(U), _f32c(mask)
+    Bsz, T, p = Y.shape
+    K, n, m = A.shape[0], A.shape[1], Bm.shape[2]
+    E = n * n + n * m + p * n
+    dev = Y.device
+    mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    mf, Sf, mp, Sp = mk(Bsz, T, n), mk(Bsz, T, n, n), mk(Bsz, T, n), mk(Bsz, T, n, n)
+    record, alpha = mk(Bsz, T, E), mk(Bsz, T, K)
+    slots = Slots(A=0, B=n * n, C=n * n + n * m)
+    call = _Call(Y, U, mask, record, None, None, None, Q, R, mu0, Sigma0, slots)
+    ws = [_f32c(t.detach()) for t in (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, head.weight,
+                                      head.bias, A, Bm, Cm)]
+    st = _states(mf, Sf, mp, Sp)
+    rc = call.lib.dll.kvae_lgssm_filter_alpha_lstm(C.byref(call.prob), C.byref(st), *[N.ptr(w) for w in ws], K,
+                                                   lstm.hidden_size, N.ptr(record), N.ptr(alpha), call.stream)
+    if rc == 1:
+        return None   # shape outside the kernel's limits: caller keeps the per-step path
+    call.lib.check(rc, "kvae_lgssm_filter_alpha_lstm")
+    return mf, Sf, mp, Sp, record, slots, alpha
+
+
+@torch.no_grad()
+def rts_only(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots, mf, Sf, mp, Sp):
+    """RTS smoother over already-filtered beliefs (kvae_lgssm_rts_fwd); no autograd."""
+    call = _Call(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots)
+    ms, Ss = torch.empty_like(mf), torch.empty_like(Sf)
+    st = _states(mf, Sf, mp, Sp, ms, Ss)
+    call.lib.check(call.lib.dll.kvae_lgssm_rts_fwd(C.byref(call.prob), C.byref(st), call.stream), "kvae_lgssm_rts_fwd")
+    return ms, Ss

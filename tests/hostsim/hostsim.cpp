@@ -292,3 +292,11 @@ int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_fram
   return KVAE_OK;
 }
 }
+
+// In-kernel alpha-network filter: gfx950-only (register-resident LSTM rows); the simulator reports it unsupported so
+// that the Python side keeps the per-step path on host tensors.
+extern "C" int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *, const kvae_lgssm_states *, const float *, const float *,
+                                            const float *, const float *, const float *, const float *, const float *,
+                                            const float *, const float *, int32_t, int32_t, float *, float *, void *) {
+  return KVAE_ERR_DIMS;
+}

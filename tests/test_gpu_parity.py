@@ -190,3 +190,32 @@ def test_bigru_gpu(B, T):
 @pytest.mark.parametrize("shape", [(256, 50, 1, 32, 32), (2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
 def test_bce_frames_gpu(shape):
     parity_cases.bce_frames_vs_torch(DEV, *shape)
+
+
+@pytest.mark.parametrize("K,T", [(3, 20), (7, 100)])
+def test_alpha_lstm_masked_matches_stepwise(K, T):
+    """In-kernel alpha-network filter (no-grad path) == the per-step differentiable path, masked frames."""
+    from kvae.model.model import KVAE
+    from kvae.utils.config import KVAEConfig
+    torch.manual_seed(K)
+    model = KVAE(KVAEConfig(dynamics_model="lstm", num_modes=K))
+    with torch.no_grad():
+        model.kalman_filter.dyn_params.A.add_(0.05 * torch.randn_like(model.kalman_filter.dyn_params.A))
+        model.kalman_filter.dyn_params.head_w.bias.zero_()
+        model.kalman_filter.dyn_params.head_w.weight.mul_(3.0)
+    kf = model.kalman_filter.to(DEV).eval()
+    B = 5
+    a = torch.randn(B, T, 2, device=DEV)
+    u = torch.zeros(B, T, 4, device=DEV)
+    mask = (torch.rand(B, T, device=DEV) > 0.4).float()
+    mask[:, :3] = 1.0
+    with torch.no_grad():
+        kf.dyn_params.reset_state()
+        fast = kf.smooth(a, u, mask=mask)
+        alpha_fast = kf.dyn_params.state_seq.clone()
+    a_g = a.clone().requires_grad_(True)     # grad-enabled call takes the per-step path
+    kf.dyn_params.reset_state()
+    slow = kf.smooth(a_g, u, mask=mask)
+    assert rel_err(alpha_fast.cpu(), kf.dyn_params.state_seq.detach().cpu()) < 2e-4
+    for f, s_ in zip(fast, slow):
+        assert rel_err(f.cpu(), s_.detach().cpu()) < 5e-4
