@@ -601,3 +601,48 @@ int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_fram
   return launch_status("k_vae_bce_bwd");
 }
 }  // extern "C"
+
+#include "vae_conv_edge.h"
+extern "C" {
+int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 768 ? (N < 1 ? 1 : N) : 768; }
+
+int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, int64_t N, int32_t Cin,
+                      int32_t side, void *stream) {
+  if (!in || !W || !bias || !logits) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cin != DH_CI || side != DH_S) return KVAE_ERR_DIMS;
+  k_dec_head_fwd<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(in, W, bias, logits);
+  return launch_status("k_dec_head_fwd");
+}
+int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, float *g_in, float *w_partials,
+                      float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream) {
+  if (!in || !W || !g_logits || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cin != DH_CI || side != DH_S) return KVAE_ERR_DIMS;
+  if (g_in) {
+    k_dec_head_bwd_data<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(g_logits, W, g_in);
+    const int rc = launch_status("k_dec_head_bwd_data");
+    if (rc) return rc;
+  }
+  k_dec_head_wrw<<<dim3((unsigned)kvae_conv_edge_partial_rows(N)), dim3(256), 0, (hipStream_t)stream>>>(in, g_logits, w_partials,
+                                                                                                     b_partials, N);
+  return launch_status("k_dec_head_wrw");
+}
+int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,
+                      int32_t side, void *stream) {
+  if (!x || !W || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cout != ES_CO || side != ES_IN) return KVAE_ERR_DIMS;
+  k_enc_stem_fwd<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out);
+  return launch_status("k_enc_stem_fwd");
+}
+int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, float *w_partials, float *b_partials,
+                      int64_t N, int32_t Cout, int32_t side, void *stream) {
+  if (!x || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cout != ES_CO || side != ES_IN) return KVAE_ERR_DIMS;
+  k_enc_stem_wrw<<<dim3((unsigned)kvae_conv_edge_partial_rows(N)), dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials,
+                                                                                                     b_partials, N);
+  return launch_status("k_enc_stem_wrw");
+}
+}  // extern "C"

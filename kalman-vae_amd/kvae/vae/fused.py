@@ -44,6 +44,80 @@ def conv_block(x, conv, r=1, relu=True):
     return BiasShuffleAct.apply(y, conv.bias, r, relu)
 
 
+class DecoderHead(torch.autograd.Function):
+    """logits[N,1,2s,2s] = pixel_shuffle_2(conv3x3(h[N,32,s,s], W[4,32,3,3]) + b) as ONE direct-convolution kernel
+    (csrc/vae_conv_edge.h; reference kvae/vae/vae.py:103-104).  A 4-output-channel implicit GEMM has nothing to
+    tile over; the direct form is bound by reading h once."""
+
+    @staticmethod
+    def supported(h, conv):
+        return (h.dim() == 4 and tuple(h.shape[1:]) == (32, 16, 16) and tuple(conv.weight.shape) == (4, 32, 3, 3)
+                and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.bias is not None)
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        h, weight, bias = h.contiguous(), weight.contiguous(), bias.contiguous()
+        Nb, Cin, s, _ = h.shape
+        logits = torch.empty(Nb, 1, 2 * s, 2 * s, device=h.device, dtype=torch.float32)
+        lib = N.lib_for(h)
+        lib.check(lib.dll.kvae_dec_head_fwd(N.ptr(h), N.ptr(weight), N.ptr(bias), N.ptr(logits), Nb, Cin, s, N.stream_for(h)),
+                  "kvae_dec_head_fwd")
+        ctx.save_for_backward(h, weight)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        h, weight = ctx.saved_tensors
+        g = g.contiguous()
+        Nb, Cin, s, _ = h.shape
+        lib = N.lib_for(h)
+        rows = lib.dll.kvae_conv_edge_partial_rows(Nb)
+        g_h = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        wp = torch.empty(rows, weight.numel(), device=h.device, dtype=torch.float32)
+        bp = torch.empty(rows, 4, device=h.device, dtype=torch.float32)
+        lib.check(lib.dll.kvae_dec_head_bwd(N.ptr(h), N.ptr(weight), N.ptr(g), N.ptr(g_h) if g_h is not None else None,
+                                            N.ptr(wp), N.ptr(bp), Nb, Cin, s, N.stream_for(h)), "kvae_dec_head_bwd")
+        return g_h, wp.sum(0).view_as(weight), bp.sum(0)
+
+
+class EncoderStem(torch.autograd.Function):
+    """out[N,32,s/2,s/2] = relu(conv3x3_stride2(x[N,1,s,s], W[32,1,3,3]) + b) as one direct kernel, and its weight /
+    bias gradient with the ReLU mask fused (reference kvae/vae/vae.py:20-31).  The frames take no gradient."""
+
+    @staticmethod
+    def supported(x, conv):
+        return (x.dim() == 4 and tuple(x.shape[1:]) == (1, 32, 32) and tuple(conv.weight.shape) == (32, 1, 3, 3)
+                and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.bias is not None and not x.requires_grad)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        Nb, _, s, _ = x.shape
+        Cout = weight.shape[0]
+        out = torch.empty(Nb, Cout, s // 2, s // 2, device=x.device, dtype=torch.float32)
+        lib = N.lib_for(x)
+        lib.check(lib.dll.kvae_enc_stem_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cout, s, N.stream_for(x)),
+                  "kvae_enc_stem_fwd")
+        ctx.save_for_backward(x, out)
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out = ctx.saved_tensors
+        g = g.contiguous()
+        Nb, Cout = out.shape[:2]
+        lib = N.lib_for(x)
+        rows = lib.dll.kvae_conv_edge_partial_rows(Nb)
+        wp = torch.empty(rows, Cout * 9, device=x.device, dtype=torch.float32)
+        bp = torch.empty(rows, Cout, device=x.device, dtype=torch.float32)
+        lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(g), N.ptr(wp), N.ptr(bp), Nb, Cout, x.shape[2],
+                                            N.stream_for(x)), "kvae_enc_stem_bwd")
+        return None, wp.sum(0).view(ctx.wshape), bp.sum(0)
+
+
 class BernoulliFrameLogLik(torch.autograd.Function):
     """[B,T] log p(x_t | a_t) = -sum_pixels BCEWithLogits(x_logits, x) (reference kvae/vae/losses.py:85-87) in one pass."""
 

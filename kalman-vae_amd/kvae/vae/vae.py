@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from kvae import _native
 from kvae.utils.config import KVAEConfig
-from kvae.vae.fused import conv_block
+from kvae.vae.fused import DecoderHead, EncoderStem, conv_block
 
 
 def _conv_out(size, k, s, p):
@@ -38,9 +38,12 @@ class Encoder(nn.Module):
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if _native.fused_ok(x) and x.dtype == torch.float32:
             h = x   # conv on MIOpen, then ONE fused bias+ReLU pass per layer (csrc/vae_epilogue.h)
-            for layer in self.conv_layers:
+            for i, layer in enumerate(self.conv_layers):
                 if isinstance(layer, nn.Conv2d):
-                    h = conv_block(h, layer, r=1, relu=True)
+                    if i == 0 and EncoderStem.supported(h, layer):   # 1 input channel: direct kernel, not a GEMM
+                        h = EncoderStem.apply(h, layer.weight, layer.bias)
+                    else:
+                        h = conv_block(h, layer, r=1, relu=True)
             feat = h.flatten(1)
         else:
             feat = self.conv_layers(x).flatten(1)
@@ -71,7 +74,10 @@ class Decoder(nn.Module):
         for i, layer in enumerate(layers):
             if isinstance(layer, nn.Conv2d):
                 relu = i + 2 < len(layers) and isinstance(layers[i + 2], nn.ReLU)
-                h = conv_block(h, layer, r=2, relu=relu)
+                if not relu and DecoderHead.supported(h, layer):     # 4 output channels: direct kernel
+                    h = DecoderHead.apply(h, layer.weight, layer.bias)
+                else:
+                    h = conv_block(h, layer, r=2, relu=relu)
         return h
 
 

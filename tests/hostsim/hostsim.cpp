@@ -300,3 +300,111 @@ extern "C" int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *, const kv
                                             const float *, const float *, int32_t, int32_t, float *, float *, void *) {
   return KVAE_ERR_DIMS;
 }
+
+// Direct convolutions of the VAE's thin layers: plain loops with the same argument checks as the HIP launchers.
+extern "C" {
+int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 768 ? (N < 1 ? 1 : N) : 768; }
+
+int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, int64_t N, int32_t Cin,
+                      int32_t side, void *) {
+  if (!in || !W || !bias || !logits) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cin != 32 || side != 16) return KVAE_ERR_DIMS;
+  const int S = side;
+  for (int64_t n = 0; n < N; ++n)
+    for (int co = 0; co < 4; ++co)
+      for (int h = 0; h < S; ++h)
+        for (int w = 0; w < S; ++w) {
+          float acc = bias[co];
+          for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int y = h + ky - 1, x = w + kx - 1;
+                if (y < 0 || y >= S || x < 0 || x >= S) continue;
+                acc += W[((co * Cin + ci) * 3 + ky) * 3 + kx] * in[((n * Cin + ci) * S + y) * S + x];
+              }
+          logits[n * 4 * S * S + (2 * h + co / 2) * 2 * S + 2 * w + (co & 1)] = acc;
+        }
+  return KVAE_OK;
+}
+int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, float *g_in, float *w_partials,
+                      float *b_partials, int64_t N, int32_t Cin, int32_t side, void *) {
+  if (!in || !W || !g_logits || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cin != 32 || side != 16) return KVAE_ERR_DIMS;
+  const int S = side;
+  const int64_t rows = kvae_conv_edge_partial_rows(N);
+  memset(w_partials, 0, sizeof(float) * rows * 4 * Cin * 9);
+  memset(b_partials, 0, sizeof(float) * rows * 4);
+  if (g_in) memset(g_in, 0, sizeof(float) * N * Cin * S * S);
+  for (int64_t n = 0; n < N; ++n) {
+    float *wp = w_partials + (n % rows) * 4 * Cin * 9, *bp = b_partials + (n % rows) * 4;
+    for (int co = 0; co < 4; ++co)
+      for (int h = 0; h < S; ++h)
+        for (int w = 0; w < S; ++w) {
+          const float g = g_logits[n * 4 * S * S + (2 * h + co / 2) * 2 * S + 2 * w + (co & 1)];
+          bp[co] += g;
+          for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int y = h + ky - 1, x = w + kx - 1;
+                if (y < 0 || y >= S || x < 0 || x >= S) continue;
+                const int64_t ii = ((n * Cin + ci) * S + y) * S + x;
+                const int wi = ((co * Cin + ci) * 3 + ky) * 3 + kx;
+                wp[wi] += g * in[ii];
+                if (g_in) g_in[ii] += g * W[wi];
+              }
+        }
+  }
+  return KVAE_OK;
+}
+int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,
+                      int32_t side, void *) {
+  if (!x || !W || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cout != 32 || side != 32) return KVAE_ERR_DIMS;
+  const int S = side, O = side / 2;
+  for (int64_t n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co)
+      for (int oh = 0; oh < O; ++oh)
+        for (int ow = 0; ow < O; ++ow) {
+          float acc = bias[co];
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const int y = 2 * oh + ky - 1, xx = 2 * ow + kx - 1;
+              if (y < 0 || y >= S || xx < 0 || xx >= S) continue;
+              acc += W[co * 9 + ky * 3 + kx] * x[(n * S + y) * S + xx];
+            }
+          out[((n * Cout + co) * O + oh) * O + ow] = acc > 0.f ? acc : 0.f;
+        }
+  return KVAE_OK;
+}
+int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, float *w_partials, float *b_partials,
+                      int64_t N, int32_t Cout, int32_t side, void *) {
+  if (!x || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cout != 32 || side != 32) return KVAE_ERR_DIMS;
+  const int S = side, O = side / 2;
+  const int64_t rows = kvae_conv_edge_partial_rows(N);
+  memset(w_partials, 0, sizeof(float) * rows * Cout * 9);
+  memset(b_partials, 0, sizeof(float) * rows * Cout);
+  for (int64_t n = 0; n < N; ++n) {
+    float *wp = w_partials + (n % rows) * Cout * 9, *bp = b_partials + (n % rows) * Cout;
+    for (int co = 0; co < Cout; ++co)
+      for (int oh = 0; oh < O; ++oh)
+        for (int ow = 0; ow < O; ++ow) {
+          const int64_t oi = ((n * Cout + co) * O + oh) * O + ow;
+          if (!(out[oi] > 0.f)) continue;
+          const float g = g_out[oi];
+          bp[co] += g;
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const int y = 2 * oh + ky - 1, xx = 2 * ow + kx - 1;
+              if (y < 0 || y >= S || xx < 0 || xx >= S) continue;
+              wp[co * 9 + ky * 3 + kx] += g * x[(n * S + y) * S + xx];
+            }
+        }
+  }
+  return KVAE_OK;
+}
+}

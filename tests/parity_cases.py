@@ -190,3 +190,38 @@ def bce_frames_vs_torch(DEV, B, T, C, H, W):
     (out * w.to(DEV)).sum().backward()
     assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
     assert rel_err(ld.grad.cpu(), lr.grad) < 1e-5
+
+
+def conv_edge_vs_torch(DEV, N):
+    """Direct decoder-head / encoder-stem kernels == conv2d (+ pixel_shuffle / relu) of torch, values and gradients.
+    Tolerance 2e-5 relative (fp32, different summation order over 288 / 9 taps and over the frames)."""
+    import torch.nn.functional as F
+    from kvae.vae.fused import DecoderHead, EncoderStem
+    g = torch.Generator().manual_seed(N)
+    h = torch.relu(torch.randn(N, 32, 16, 16, generator=g))
+    W = 0.1 * torch.randn(4, 32, 3, 3, generator=g)
+    b = torch.randn(4, generator=g)
+    up = torch.randn(N, 1, 32, 32, generator=g)
+    hr, Wr, br = (t.clone().requires_grad_(True) for t in (h, W, b))
+    ref = F.pixel_shuffle(F.conv2d(hr, Wr, br, padding=1), 2)
+    (ref * up).sum().backward()
+    hd, Wd, bd = (t.clone().to(DEV).requires_grad_(True) for t in (h, W, b))
+    out = DecoderHead.apply(hd, Wd, bd)
+    (out * up.to(DEV)).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    for a, r in ((hd, hr), (Wd, Wr), (bd, br)):
+        assert rel_err(a.grad.cpu(), r.grad) < 2e-5
+
+    x = torch.rand(N, 1, 32, 32, generator=g)
+    W = 0.3 * torch.randn(32, 1, 3, 3, generator=g)
+    b = 0.1 * torch.randn(32, generator=g)
+    up = torch.randn(N, 32, 16, 16, generator=g)
+    Wr, br = (t.clone().requires_grad_(True) for t in (W, b))
+    ref = torch.relu(F.conv2d(x, Wr, br, stride=2, padding=1))
+    (ref * up).sum().backward()
+    Wd, bd = (t.clone().to(DEV).requires_grad_(True) for t in (W, b))
+    out = EncoderStem.apply(x.to(DEV), Wd, bd)
+    (out * up.to(DEV)).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < 2e-5
+    for a, r in ((Wd, Wr), (bd, br)):
+        assert rel_err(a.grad.cpu(), r.grad) < 2e-5

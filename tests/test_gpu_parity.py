@@ -187,6 +187,12 @@ def test_bigru_gpu(B, T):
         assert rel_err(got.grad.cpu(), getattr(ref, n).grad) < 2e-4, n
 
 
+@pytest.mark.parametrize("N", [1, 37, 1000, 2000])
+def test_conv_edge_gpu(N):
+    """Direct decoder-head / encoder-stem kernels vs torch conv2d; 1000 / 2000 frames exercise the frame-strided weight-gradient loop."""
+    parity_cases.conv_edge_vs_torch(DEV, N)
+
+
 @pytest.mark.parametrize("shape", [(256, 50, 1, 32, 32), (2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
 def test_bce_frames_gpu(shape):
     parity_cases.bce_frames_vs_torch(DEV, *shape)

@@ -167,6 +167,12 @@ def test_regime_hostsim(B, T, K, tau, hard):
     parity_cases.regime_vs_torch("cpu", B, T, K, tau, hard)
 
 
+@pytest.mark.parametrize("N", [1, 5])
+def test_conv_edge_hostsim(N):
+    import parity_cases
+    parity_cases.conv_edge_vs_torch("cpu", N)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
 def test_bce_frames_hostsim(shape):
     import parity_cases
