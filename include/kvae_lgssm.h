@@ -220,12 +220,13 @@ int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_fram
 /* Decoder head (kvae/vae/vae.py:103-104): logits[N,1,2s,2s] = pixel_shuffle_2(conv3x3_pad1(in[N,Cin,s,s], W[4,Cin,3,3]) + b[4]).
  * Built for Cin = 32, s = 16 (the reference's default decoder); other shapes return KVAE_ERR_DIMS and the caller
  * keeps the library convolution. */
-int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, int64_t N, int32_t Cin,
-                      int32_t side, void *stream);
+#define KVAE_DEC_HEAD_SCRATCH_FLOATS 2304 /* caller-owned scratch: the weights re-laid for scalar loads */
+int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, float *w_scratch, int64_t N,
+                      int32_t Cin, int32_t side, void *stream);
 /* g_in[N,Cin,s,s] (data gradient; may be NULL to skip), w_partials [kvae_conv_edge_partial_rows(N), 4*Cin*9] and
  * b_partials [rows, 4]: the weight / bias gradients are their column sums. */
 int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, float *g_in, float *w_partials,
-                      float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream);
+                      float *b_partials, float *w_scratch, int64_t N, int32_t Cin, int32_t side, void *stream);
 /* Encoder stem (kvae/vae/vae.py:20-31): out[N,Cout,s/2,s/2] = relu(conv3x3_stride2_pad1(x[N,1,s,s], W[Cout,1,3,3]) + b).
  * Built for Cout = 32, s = 32. */
 int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,

@@ -606,21 +606,23 @@ int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_fram
 extern "C" {
 int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 768 ? (N < 1 ? 1 : N) : 768; }
 
-int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, int64_t N, int32_t Cin,
-                      int32_t side, void *stream) {
-  if (!in || !W || !bias || !logits) return KVAE_ERR_NULL;
+int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, float *w_scratch, int64_t N,
+                      int32_t Cin, int32_t side, void *stream) {
+  if (!in || !W || !bias || !logits || !w_scratch) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cin != DH_CI || side != DH_S) return KVAE_ERR_DIMS;
-  k_dec_head_fwd<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(in, W, bias, logits);
+  k_dec_head_prep<<<dim3(1), dim3(256), 0, (hipStream_t)stream>>>(W, w_scratch);
+  k_dec_head_fwd<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(in, w_scratch, bias, logits);
   return launch_status("k_dec_head_fwd");
 }
 int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, float *g_in, float *w_partials,
-                      float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream) {
-  if (!in || !W || !g_logits || !w_partials || !b_partials) return KVAE_ERR_NULL;
+                      float *b_partials, float *w_scratch, int64_t N, int32_t Cin, int32_t side, void *stream) {
+  if (!in || !W || !g_logits || !w_partials || !b_partials || !w_scratch) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cin != DH_CI || side != DH_S) return KVAE_ERR_DIMS;
   if (g_in) {
-    k_dec_head_bwd_data<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(g_logits, W, g_in);
+    k_dec_head_prep<<<dim3(1), dim3(256), 0, (hipStream_t)stream>>>(W, w_scratch);
+    k_dec_head_bwd_data<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(g_logits, w_scratch, g_in);
     const int rc = launch_status("k_dec_head_bwd_data");
     if (rc) return rc;
   }

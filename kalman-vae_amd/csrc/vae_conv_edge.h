@@ -18,28 +18,54 @@ namespace kvae {
 // decoder head: in [N,32,16,16] -> logits [N,1,32,32] = pixel_shuffle_2(conv3x3(in, W[4,32,3,3]) + b[4])
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DH_CI = 32, DH_CO = 4, DH_S = 16, DH_TS = 18, DH_CS = 325;   // tile side with halo, padded channel stride
+constexpr int DH_W = DH_CO * DH_CI * 9;                                    // 1152 weights
+typedef float kv_f2 __attribute__((ext_vector_type(2)));
+typedef float kv_f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void dh_load_tile(float *tile, const float *__restrict__ src) {
-  for (int i = threadIdx.x; i < DH_CI * DH_CS; i += 256) tile[i] = 0.f;
-  __syncthreads();
-  for (int i = threadIdx.x; i < DH_CI * DH_S * DH_S / 4; i += 256) {
-    const float4 v = reinterpret_cast<const float4 *>(src)[i];
-    const int e = i * 4, ci = e >> 8, hw = e & 255, h = hw >> 4, w = hw & 15;
-    float *d = tile + ci * DH_CS + (h + 1) * DH_TS + (w + 1);
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+// Weights re-laid for wide scalar loads and packed FMAs: scratch[0:1152] = Wf[ci][k][co] (forward: the 4 output
+// channels of one tap are one s_load_dwordx4), scratch[1152:2304] = Wb[co][k][ci] (data gradient: the 32 input
+// channels of one tap are two s_load_dwordx16).
+__global__ __launch_bounds__(256) void k_dec_head_prep(const float *__restrict__ W, float *__restrict__ scratch) {
+  for (int i = threadIdx.x; i < DH_W; i += 256) {
+    const int co = i / (DH_CI * 9), r = i - co * DH_CI * 9, ci = r / 9, k = r - ci * 9;
+    const float w = W[i];
+    scratch[(ci * 9 + k) * DH_CO + co] = w;
+    scratch[DH_W + (co * 9 + k) * DH_CI + ci] = w;
   }
 }
 
-__global__ __launch_bounds__(256) void k_dec_head_fwd(const float *__restrict__ in, const float *__restrict__ W,
+__device__ __forceinline__ void dh_zero_halo(float *tile, int channels) {
+  for (int i = threadIdx.x; i < channels * 68; i += 256) {
+    const int c = i / 68, j = i - c * 68;
+    int r, q;
+    if (j < 18) { r = 0; q = j; }
+    else if (j < 36) { r = 17; q = j - 18; }
+    else if (j < 52) { r = j - 35; q = 0; }
+    else { r = j - 51; q = 17; }
+    tile[c * DH_CS + r * DH_TS + q] = 0.f;
+  }
+}
+__device__ __forceinline__ void dh_store_interior(float *tile, int i, const float4 v) {   // i = float4 index in [32,16,16]
+  const int e = i * 4, ci = e >> 8, hw = e & 255, h = hw >> 4, w = hw & 15;
+  float *d = tile + ci * DH_CS + (h + 1) * DH_TS + (w + 1);
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+
+__global__ __launch_bounds__(256) void k_dec_head_fwd(const float *__restrict__ in, const float *__restrict__ scratch,
                                                       const float *__restrict__ bias, float *__restrict__ logits) {
   __shared__ float tile[DH_CI * DH_CS];
   const int64_t n = blockIdx.x;
-  dh_load_tile(tile, in + n * DH_CI * 256);
+  const float4 *src = reinterpret_cast<const float4 *>(in + n * DH_CI * 256);
+  float4 pre[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pre[j] = src[threadIdx.x + 256 * j];
+  dh_zero_halo(tile, DH_CI);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dh_store_interior(tile, threadIdx.x + 256 * j, pre[j]);
   __syncthreads();
   const int h = threadIdx.x >> 4, w = threadIdx.x & 15;
-  float acc[DH_CO];
-#pragma unroll
-  for (int co = 0; co < DH_CO; ++co) acc[co] = bias[co];
+  kv_f2 a01 = {bias[0], bias[1]}, a23 = {bias[2], bias[3]};
+  const kv_f4 *Wf = reinterpret_cast<const kv_f4 *>(scratch);
 #pragma unroll 4
   for (int ci = 0; ci < DH_CI; ++ci) {
     const float *t = tile + ci * DH_CS + h * DH_TS + w;
@@ -48,82 +74,113 @@ __global__ __launch_bounds__(256) void k_dec_head_fwd(const float *__restrict__ 
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const float v = t[ky * DH_TS + kx];
-#pragma unroll
-        for (int co = 0; co < DH_CO; ++co) acc[co] = fmaf(W[((co * DH_CI + ci) * 3 + ky) * 3 + kx], v, acc[co]);
+        const kv_f4 wv = Wf[ci * 9 + ky * 3 + kx];
+        a01 += wv.xy * v;
+        a23 += wv.zw * v;
       }
   }
   float *o = logits + n * 1024 + (2 * h) * 32 + 2 * w;          // co = 2*dy + dx -> pixel (2h+dy, 2w+dx)
-  *reinterpret_cast<float2 *>(o) = make_float2(acc[0], acc[1]);
-  *reinterpret_cast<float2 *>(o + 32) = make_float2(acc[2], acc[3]);
+  *reinterpret_cast<float2 *>(o) = make_float2(a01.x, a01.y);
+  *reinterpret_cast<float2 *>(o + 32) = make_float2(a23.x, a23.y);
 }
 
 // g_in[n,ci,h,w] = sum_{co,ky,kx} W[co,ci,ky,kx] g_conv[n,co,h-ky+1,w-kx+1],  g_conv = pixel_unshuffle(g_logits)
-__global__ __launch_bounds__(256) void k_dec_head_bwd_data(const float *__restrict__ g_logits, const float *__restrict__ W,
-                                                           float *__restrict__ g_in) {
+__global__ __launch_bounds__(256) void k_dec_head_bwd_data(const float *__restrict__ g_logits,
+                                                           const float *__restrict__ scratch, float *__restrict__ g_in) {
   __shared__ float gt[DH_CO * DH_CS];
   const int64_t n = blockIdx.x;
-  for (int i = threadIdx.x; i < DH_CO * DH_CS; i += 256) gt[i] = 0.f;
-  __syncthreads();
-  for (int i = threadIdx.x; i < 1024; i += 256) {
-    const int oh = i >> 5, ow = i & 31, co = (oh & 1) * 2 + (ow & 1);
-    gt[co * DH_CS + ((oh >> 1) + 1) * DH_TS + (ow >> 1) + 1] = g_logits[n * 1024 + i];
+  float gp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gp[j] = g_logits[n * 1024 + threadIdx.x + 256 * j];
+  dh_zero_halo(gt, DH_CO);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = threadIdx.x + 256 * j, oh = i >> 5, ow = i & 31, co = (oh & 1) * 2 + (ow & 1);
+    gt[co * DH_CS + ((oh >> 1) + 1) * DH_TS + (ow >> 1) + 1] = gp[j];
   }
   __syncthreads();
   const int h = threadIdx.x >> 4, w = threadIdx.x & 15;
-  float g[DH_CO][9];
+  kv_f2 acc[DH_CI / 2];
+#pragma unroll
+  for (int j = 0; j < DH_CI / 2; ++j) acc[j] = kv_f2{0.f, 0.f};
+  const kv_f2 *Wb = reinterpret_cast<const kv_f2 *>(scratch + DH_W);
 #pragma unroll
   for (int co = 0; co < DH_CO; ++co)
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) g[co][ky * 3 + kx] = gt[co * DH_CS + (h + 2 - ky) * DH_TS + (w + 2 - kx)];
+      for (int kx = 0; kx < 3; ++kx) {
+        const float v = gt[co * DH_CS + (h + 2 - ky) * DH_TS + (w + 2 - kx)];
+        const kv_f2 *wr = Wb + (co * 9 + ky * 3 + kx) * (DH_CI / 2);
+#pragma unroll
+        for (int j = 0; j < DH_CI / 2; ++j) acc[j] += wr[j] * v;
+      }
   float *o = g_in + n * DH_CI * 256 + threadIdx.x;
-#pragma unroll 4
-  for (int ci = 0; ci < DH_CI; ++ci) {
-    float acc = 0.f;
 #pragma unroll
-    for (int co = 0; co < DH_CO; ++co)
-#pragma unroll
-      for (int k = 0; k < 9; ++k) acc = fmaf(W[(co * DH_CI + ci) * 9 + k], g[co][k], acc);
-    o[ci * 256] = acc;
+  for (int j = 0; j < DH_CI / 2; ++j) {
+    o[(2 * j) * 256] = acc[j].x;
+    o[(2 * j + 1) * 256] = acc[j].y;
   }
 }
 
 // partial[blk, co, ci, k] = sum over this block's frames of sum_{h,w} g_conv[n,co,h,w] in[n,ci,h+ky-1,w+kx-1];
-// partial_b[blk, co] = sum g_conv.  Thread = (ci = tid & 31, pixel group = tid >> 5: 32 pixels each).
+// partial_b[blk, co] = sum g_conv.  Thread = (ci = tid & 31, pixel group = tid >> 5: 32 pixels each).  The next
+// frame is fetched into registers while the current one is being reduced out of LDS.
 __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ in, const float *__restrict__ g_logits,
                                                       float *__restrict__ partial, float *__restrict__ partial_b, int64_t N) {
   __shared__ float tile[DH_CI * DH_CS];
   __shared__ float gt[DH_CO * 256];
   const int ci = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  float acc[DH_CO][9], accb[DH_CO];
+  kv_f2 acc[DH_CO / 2][9];
+  float accb[DH_CO];
 #pragma unroll
-  for (int co = 0; co < DH_CO; ++co) {
-    accb[co] = 0.f;
+  for (int c = 0; c < DH_CO / 2; ++c)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[co][k] = 0.f;
+    for (int k = 0; k < 9; ++k) acc[c][k] = kv_f2{0.f, 0.f};
+#pragma unroll
+  for (int co = 0; co < DH_CO; ++co) accb[co] = 0.f;
+  dh_zero_halo(tile, DH_CI);
+  float4 pre[8];
+  float gp[4];
+  int64_t n = blockIdx.x;
+  if (n < N) {
+    const float4 *src = reinterpret_cast<const float4 *>(in + n * DH_CI * 256);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pre[j] = src[threadIdx.x + 256 * j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gp[j] = g_logits[n * 1024 + threadIdx.x + 256 * j];
   }
-  for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+  for (; n < N; n += gridDim.x) {
     __syncthreads();                                  // previous frame's tile fully consumed
-    dh_load_tile(tile, in + n * DH_CI * 256);
-    for (int i = threadIdx.x; i < 1024; i += 256) {
-      const int oh = i >> 5, ow = i & 31, co = (oh & 1) * 2 + (ow & 1);
-      gt[co * 256 + (oh >> 1) * 16 + (ow >> 1)] = g_logits[n * 1024 + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dh_store_interior(tile, threadIdx.x + 256 * j, pre[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = threadIdx.x + 256 * j, oh = i >> 5, ow = i & 31, co = (oh & 1) * 2 + (ow & 1);
+      gt[co * 256 + (oh >> 1) * 16 + (ow >> 1)] = gp[j];
     }
     __syncthreads();
+    const int64_t nn = n + gridDim.x;
+    if (nn < N) {
+      const float4 *src = reinterpret_cast<const float4 *>(in + nn * DH_CI * 256);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pre[j] = src[threadIdx.x + 256 * j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gp[j] = g_logits[nn * 1024 + threadIdx.x + 256 * j];
+    }
+#pragma unroll 2
     for (int i = 0; i < 32; ++i) {
       const int hw = grp * 32 + i, h = hw >> 4, w = hw & 15;
-      float gv[DH_CO];
-#pragma unroll
-      for (int co = 0; co < DH_CO; ++co) { gv[co] = gt[co * 256 + hw]; accb[co] += gv[co]; }
+      const kv_f2 g01 = {gt[hw], gt[256 + hw]}, g23 = {gt[512 + hw], gt[768 + hw]};
+      accb[0] += g01.x; accb[1] += g01.y; accb[2] += g23.x; accb[3] += g23.y;
       const float *t = tile + ci * DH_CS + h * DH_TS + w;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const float v = t[ky * DH_TS + kx];
-#pragma unroll
-          for (int co = 0; co < DH_CO; ++co) acc[co][ky * 3 + kx] = fmaf(gv[co], v, acc[co][ky * 3 + kx]);
+          acc[0][ky * 3 + kx] += g01 * v;
+          acc[1][ky * 3 + kx] += g23 * v;
         }
     }
   }
@@ -131,19 +188,20 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   // reduce the 8 pixel groups through LDS (reuse tile: 8 * 32 * 36 floats = 9216 <= 10400)
   float *red = tile;
 #pragma unroll
-  for (int co = 0; co < DH_CO; ++co)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) red[(grp * 32 + ci) * 36 + co * 9 + k] = acc[co][k];
+  for (int k = 0; k < 9; ++k) {
+    float *r = red + (grp * 32 + ci) * 36 + k;
+    r[0] = acc[0][k].x; r[9] = acc[0][k].y; r[18] = acc[1][k].x; r[27] = acc[1][k].y;
+  }
   if (ci == 0) {
 #pragma unroll
     for (int co = 0; co < DH_CO; ++co) gt[grp * 4 + co] = accb[co];
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < DH_CO * DH_CI * 9; o += 256) {
+  for (int o = threadIdx.x; o < DH_W; o += 256) {
     const int co = o / (DH_CI * 9), r = o - co * DH_CI * 9, c2 = r / 9, k = r - c2 * 9;
     float s = 0.f;
     for (int gq = 0; gq < 8; ++gq) s += red[(gq * 32 + c2) * 36 + co * 9 + k];
-    partial[(int64_t)blockIdx.x * (DH_CO * DH_CI * 9) + o] = s;
+    partial[(int64_t)blockIdx.x * DH_W + o] = s;
   }
   if (threadIdx.x < DH_CO) {
     float s = 0.f;

@@ -34,9 +34,10 @@ class Trainer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=torch.float32)
-        off = 0
+        off, self.grad_views = 0, []
         for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            p.grad = self.grad_views[-1]
             off += p.numel()
         on_gpu = dev.type == "cuda"
         self.opt = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
@@ -55,13 +56,25 @@ class Trainer:
 
     # -- the three segments of a step ---------------------------------------------------------------
     def _forward_backward(self, x):
-        self.flat_grad.zero_()
+        for p in self.params:   # autograd then hands over each gradient tensor as is (no per-parameter add kernel)
+            p.grad = None
         self.model.kalman_filter.dyn_params.reset_state()
         outputs = self.model(x, mask=None, with_recon=False)   # all frames observed == mask of ones (train.py:41)
         losses = self.model.compute_loss(x, outputs, kf_weight=self.kf_weight, vae_weight=self.vae_weight, mask=None,
                                          with_metrics=False)
         losses["loss"].backward()
+        self._gather_grads()
         self.out = {k: losses[k].detach() for k in ("loss", "elbo_kf", "elbo_vae_total")}
+
+    def _gather_grads(self):
+        """All gradients into the flat buffer with ONE multi-tensor copy; p.grad becomes the flat view again."""
+        got = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        if got:
+            torch._foreach_copy_([v for v, _ in got], [g for _, g in got])
+        for v, p in zip(self.grad_views, self.params):
+            if p.grad is None:
+                v.zero_()
+            p.grad = v
 
     def _allreduce(self):
         if self.world > 1:

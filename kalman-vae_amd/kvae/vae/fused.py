@@ -49,6 +49,8 @@ class DecoderHead(torch.autograd.Function):
     (csrc/vae_conv_edge.h; reference kvae/vae/vae.py:103-104).  A 4-output-channel implicit GEMM has nothing to
     tile over; the direct form is bound by reading h once."""
 
+    SCRATCH = 2304   # KVAE_DEC_HEAD_SCRATCH_FLOATS
+
     @staticmethod
     def supported(h, conv):
         return (h.dim() == 4 and tuple(h.shape[1:]) == (32, 16, 16) and tuple(conv.weight.shape) == (4, 32, 3, 3)
@@ -60,9 +62,10 @@ class DecoderHead(torch.autograd.Function):
         h, weight, bias = h.contiguous(), weight.contiguous(), bias.contiguous()
         Nb, Cin, s, _ = h.shape
         logits = torch.empty(Nb, 1, 2 * s, 2 * s, device=h.device, dtype=torch.float32)
+        scratch = torch.empty(DecoderHead.SCRATCH, device=h.device, dtype=torch.float32)
         lib = N.lib_for(h)
-        lib.check(lib.dll.kvae_dec_head_fwd(N.ptr(h), N.ptr(weight), N.ptr(bias), N.ptr(logits), Nb, Cin, s, N.stream_for(h)),
-                  "kvae_dec_head_fwd")
+        lib.check(lib.dll.kvae_dec_head_fwd(N.ptr(h), N.ptr(weight), N.ptr(bias), N.ptr(logits), N.ptr(scratch), Nb, Cin, s,
+                                            N.stream_for(h)), "kvae_dec_head_fwd")
         ctx.save_for_backward(h, weight)
         return logits
 
@@ -76,8 +79,10 @@ class DecoderHead(torch.autograd.Function):
         g_h = torch.empty_like(h) if ctx.needs_input_grad[0] else None
         wp = torch.empty(rows, weight.numel(), device=h.device, dtype=torch.float32)
         bp = torch.empty(rows, 4, device=h.device, dtype=torch.float32)
+        scratch = torch.empty(DecoderHead.SCRATCH, device=h.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_dec_head_bwd(N.ptr(h), N.ptr(weight), N.ptr(g), N.ptr(g_h) if g_h is not None else None,
-                                            N.ptr(wp), N.ptr(bp), Nb, Cin, s, N.stream_for(h)), "kvae_dec_head_bwd")
+                                            N.ptr(wp), N.ptr(bp), N.ptr(scratch), Nb, Cin, s, N.stream_for(h)),
+                  "kvae_dec_head_bwd")
         return g_h, wp.sum(0).view_as(weight), bp.sum(0)
 
 

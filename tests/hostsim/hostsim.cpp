@@ -305,9 +305,9 @@ extern "C" int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *, const kv
 extern "C" {
 int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 768 ? (N < 1 ? 1 : N) : 768; }
 
-int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, int64_t N, int32_t Cin,
-                      int32_t side, void *) {
-  if (!in || !W || !bias || !logits) return KVAE_ERR_NULL;
+int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, float *w_scratch, int64_t N,
+                      int32_t Cin, int32_t side, void *) {
+  if (!in || !W || !bias || !logits || !w_scratch) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cin != 32 || side != 16) return KVAE_ERR_DIMS;
   const int S = side;
@@ -328,8 +328,8 @@ int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float 
   return KVAE_OK;
 }
 int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, float *g_in, float *w_partials,
-                      float *b_partials, int64_t N, int32_t Cin, int32_t side, void *) {
-  if (!in || !W || !g_logits || !w_partials || !b_partials) return KVAE_ERR_NULL;
+                      float *b_partials, float *w_scratch, int64_t N, int32_t Cin, int32_t side, void *) {
+  if (!in || !W || !g_logits || !w_partials || !b_partials || !w_scratch) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cin != 32 || side != 16) return KVAE_ERR_DIMS;
   const int S = side;
