@@ -237,6 +237,16 @@ int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, floa
                       int64_t N, int32_t Cout, int32_t side, void *stream);
 int64_t kvae_conv_edge_partial_rows(int64_t N);
 
+/* Encoder middle layers (kvae/vae/vae.py:20-31): out[N,32,s/2,s/2] = relu(conv3x3_stride2_pad1(in[N,32,s,s], W[32,32,3,3]) + b)
+ * on the f32 matrix cores.  Built for C = 32 and s in {16, 8}; other shapes return KVAE_ERR_DIMS. */
+int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *out, int64_t N, int32_t C, int32_t side,
+                     void *stream);
+/* g_in[N,32,s,s] (may be NULL) = data gradient of g_out * (out > 0); w_partials [rows, 32*32*9] and
+ * b_partials [2*rows, 32] with rows = kvae_enc_mid_partial_rows(N, side): gradients are the column sums. */
+int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const float *g_out, float *g_in,
+                     float *w_partials, float *b_partials, int64_t N, int32_t C, int32_t side, void *stream);
+int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

@@ -648,3 +648,39 @@ int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, floa
   return launch_status("k_enc_stem_wrw");
 }
 }  // extern "C"
+
+#include "vae_conv_mid.h"
+static inline int64_t enc_mid_grid(int64_t N, int32_t side) {
+  const int64_t fpi = side == 16 ? 2 : 8, iters = (N + fpi - 1) / fpi;
+  return iters < 256 ? (iters < 1 ? 1 : iters) : 256;   // one persistent workgroup per CU
+}
+extern "C" {
+int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side) { return enc_mid_grid(N, side) * 4; }
+
+int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *out, int64_t N, int32_t C, int32_t side,
+                     void *stream) {
+  if (!in || !W || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (C != EM_C || (side != 16 && side != 8)) return KVAE_ERR_DIMS;
+  const dim3 grid((unsigned)enc_mid_grid(N, side));
+  if (side == 16) k_enc_mid_fwd<16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(in, W, bias, out, N);
+  else k_enc_mid_fwd<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(in, W, bias, out, N);
+  return launch_status("k_enc_mid_fwd");
+}
+int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const float *g_out, float *g_in,
+                     float *w_partials, float *b_partials, int64_t N, int32_t C, int32_t side, void *stream) {
+  if (!in || !W || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (C != EM_C || (side != 16 && side != 8)) return KVAE_ERR_DIMS;
+  const dim3 grid((unsigned)enc_mid_grid(N, side));
+  if (g_in) {
+    if (side == 16) k_enc_mid_bwd_data<16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_in, N);
+    else k_enc_mid_bwd_data<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_in, N);
+    const int rc = launch_status("k_enc_mid_bwd_data");
+    if (rc) return rc;
+  }
+  if (side == 16) k_enc_mid_wrw<16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(in, out, g_out, w_partials, b_partials, N);
+  else k_enc_mid_wrw<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(in, out, g_out, w_partials, b_partials, N);
+  return launch_status("k_enc_mid_wrw");
+}
+}  // extern "C"

@@ -123,6 +123,42 @@ class EncoderStem(torch.autograd.Function):
         return None, wp.sum(0).view(ctx.wshape), bp.sum(0)
 
 
+class EncoderMid(torch.autograd.Function):
+    """out[N,32,s/2,s/2] = relu(conv3x3_stride2(x[N,32,s,s], W[32,32,3,3]) + b), s in {16, 8}, as implicit GEMMs on the
+    exact-f32 matrix cores (csrc/vae_conv_mid.h; reference kvae/vae/vae.py:20-31).  Backward fuses the ReLU mask."""
+
+    @staticmethod
+    def supported(x, conv):
+        return (x.dim() == 4 and x.shape[1] == 32 and x.shape[2] == x.shape[3] and x.shape[2] in (16, 8)
+                and tuple(conv.weight.shape) == (32, 32, 3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        Nb, Cc, s, _ = x.shape
+        out = torch.empty(Nb, Cc, s // 2, s // 2, device=x.device, dtype=torch.float32)
+        lib = N.lib_for(x)
+        lib.check(lib.dll.kvae_enc_mid_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cc, s, N.stream_for(x)),
+                  "kvae_enc_mid_fwd")
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        g = g.contiguous()
+        Nb, Cc, s, _ = x.shape
+        lib = N.lib_for(x)
+        rows = lib.dll.kvae_enc_mid_partial_rows(Nb, s)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
+        bp = torch.empty(2 * rows, Cc, device=x.device, dtype=torch.float32)
+        lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
+                                           N.ptr(wp), N.ptr(bp), Nb, Cc, s, N.stream_for(x)), "kvae_enc_mid_bwd")
+        return g_x, wp.sum(0).view_as(weight), bp.sum(0)
+
+
 class BernoulliFrameLogLik(torch.autograd.Function):
     """[B,T] log p(x_t | a_t) = -sum_pixels BCEWithLogits(x_logits, x) (reference kvae/vae/losses.py:85-87) in one pass."""
 

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from kvae import _native
 from kvae.utils.config import KVAEConfig
-from kvae.vae.fused import DecoderHead, EncoderStem, conv_block
+from kvae.vae.fused import DecoderHead, EncoderMid, EncoderStem, conv_block
 
 
 def _conv_out(size, k, s, p):
@@ -42,6 +42,8 @@ class Encoder(nn.Module):
                 if isinstance(layer, nn.Conv2d):
                     if i == 0 and EncoderStem.supported(h, layer):   # 1 input channel: direct kernel, not a GEMM
                         h = EncoderStem.apply(h, layer.weight, layer.bias)
+                    elif EncoderMid.supported(h, layer):             # stride 2: implicit GEMM on the f32 matrix cores
+                        h = EncoderMid.apply(h, layer.weight, layer.bias)
                     else:
                         h = conv_block(h, layer, r=1, relu=True)
             feat = h.flatten(1)

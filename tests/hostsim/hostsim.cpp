@@ -408,3 +408,68 @@ int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, floa
   return KVAE_OK;
 }
 }
+
+// Encoder middle layers (stride-2 3x3, 32 -> 32, + ReLU): plain loops with the HIP launchers' argument checks.
+extern "C" {
+static int64_t enc_mid_grid_sim(int64_t N, int32_t side) {
+  const int64_t fpi = side == 16 ? 2 : 8, iters = (N + fpi - 1) / fpi;
+  return iters < 256 ? (iters < 1 ? 1 : iters) : 256;
+}
+int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side) { return enc_mid_grid_sim(N, side) * 4; }
+
+int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *out, int64_t N, int32_t C, int32_t side,
+                     void *) {
+  if (!in || !W || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (C != 32 || (side != 16 && side != 8)) return KVAE_ERR_DIMS;
+  const int S = side, O = side / 2;
+  for (int64_t n = 0; n < N; ++n)
+    for (int co = 0; co < C; ++co)
+      for (int oh = 0; oh < O; ++oh)
+        for (int ow = 0; ow < O; ++ow) {
+          float acc = bias[co];
+          for (int ci = 0; ci < C; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int y = 2 * oh + ky - 1, x = 2 * ow + kx - 1;
+                if (y < 0 || y >= S || x < 0 || x >= S) continue;
+                acc += W[((co * C + ci) * 3 + ky) * 3 + kx] * in[((n * C + ci) * S + y) * S + x];
+              }
+          out[((n * C + co) * O + oh) * O + ow] = acc > 0.f ? acc : 0.f;
+        }
+  return KVAE_OK;
+}
+int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const float *g_out, float *g_in,
+                     float *w_partials, float *b_partials, int64_t N, int32_t C, int32_t side, void *) {
+  if (!in || !W || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (C != 32 || (side != 16 && side != 8)) return KVAE_ERR_DIMS;
+  const int S = side, O = side / 2;
+  const int64_t rows = kvae_enc_mid_partial_rows(N, side);
+  memset(w_partials, 0, sizeof(float) * rows * C * C * 9);
+  memset(b_partials, 0, sizeof(float) * 2 * rows * C);
+  if (g_in) memset(g_in, 0, sizeof(float) * N * C * S * S);
+  for (int64_t n = 0; n < N; ++n) {
+    float *wp = w_partials + (n % rows) * C * C * 9, *bp = b_partials + (n % (2 * rows)) * C;
+    for (int co = 0; co < C; ++co)
+      for (int oh = 0; oh < O; ++oh)
+        for (int ow = 0; ow < O; ++ow) {
+          const int64_t oi = ((n * C + co) * O + oh) * O + ow;
+          if (!(out[oi] > 0.f)) continue;
+          const float g = g_out[oi];
+          bp[co] += g;
+          for (int ci = 0; ci < C; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int y = 2 * oh + ky - 1, x = 2 * ow + kx - 1;
+                if (y < 0 || y >= S || x < 0 || x >= S) continue;
+                const int64_t ii = ((n * C + ci) * S + y) * S + x;
+                const int wi = ((co * C + ci) * 3 + ky) * 3 + kx;
+                wp[wi] += g * in[ii];
+                if (g_in) g_in[ii] += g * W[wi];
+              }
+        }
+  }
+  return KVAE_OK;
+}
+}

@@ -225,3 +225,24 @@ def conv_edge_vs_torch(DEV, N):
     assert rel_err(out.detach().cpu(), ref.detach()) < 2e-5
     for a, r in ((Wd, Wr), (bd, br)):
         assert rel_err(a.grad.cpu(), r.grad) < 2e-5
+
+
+def enc_mid_vs_torch(DEV, N, side):
+    """MFMA stride-2 encoder layers == relu(conv2d(stride 2)) of torch, values and all three gradients.  Tolerance 3e-5
+    relative: exact-f32 MFMA is a k-ordered fmaf chain, torch's conv sums the 288 taps in another order."""
+    import torch.nn.functional as F
+    from kvae.vae.fused import EncoderMid
+    g = torch.Generator().manual_seed(N * side)
+    x = torch.relu(torch.randn(N, 32, side, side, generator=g))
+    W = 0.08 * torch.randn(32, 32, 3, 3, generator=g)
+    b = 0.1 * torch.randn(32, generator=g)
+    up = torch.randn(N, 32, side // 2, side // 2, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    ref = torch.relu(F.conv2d(xr, Wr, br, stride=2, padding=1))
+    (ref * up).sum().backward()
+    xd, Wd, bd = (t.clone().to(DEV).requires_grad_(True) for t in (x, W, b))
+    out = EncoderMid.apply(xd, Wd, bd)
+    (out * up.to(DEV)).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < 3e-5
+    for a, r in ((xd, xr), (Wd, Wr), (bd, br)):
+        assert rel_err(a.grad.cpu(), r.grad) < 3e-5

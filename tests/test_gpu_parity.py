@@ -193,6 +193,13 @@ def test_conv_edge_gpu(N):
     parity_cases.conv_edge_vs_torch(DEV, N)
 
 
+@pytest.mark.parametrize("N,side", [(1, 16), (2, 16), (7, 16), (1031, 16), (1, 8), (8, 8), (13, 8), (4099, 8)])
+def test_enc_mid_gpu(N, side):
+    """MFMA stride-2 encoder layers vs torch; odd frame counts exercise the ragged last iteration, the large ones the
+    persistent loop (more iterations than workgroups)."""
+    parity_cases.enc_mid_vs_torch(DEV, N, side)
+
+
 @pytest.mark.parametrize("shape", [(256, 50, 1, 32, 32), (2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
 def test_bce_frames_gpu(shape):
     parity_cases.bce_frames_vs_torch(DEV, *shape)

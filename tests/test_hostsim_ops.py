@@ -173,6 +173,12 @@ def test_conv_edge_hostsim(N):
     parity_cases.conv_edge_vs_torch("cpu", N)
 
 
+@pytest.mark.parametrize("N,side", [(3, 16), (9, 8)])
+def test_enc_mid_hostsim(N, side):
+    import parity_cases
+    parity_cases.enc_mid_vs_torch("cpu", N, side)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
 def test_bce_frames_hostsim(shape):
     import parity_cases

@@ -47,3 +47,19 @@ print(f"enc_stem bwd           {timed(lambda: torch.autograd.grad(oe, (We, be), 
 re_ = torch.relu(F.conv2d(x, We, be, stride=2, padding=1))
 print(f"miopen   fwd+relu      {timed(lambda: torch.relu(F.conv2d(x, We, be, stride=2, padding=1))):8.1f} us")
 print(f"miopen   bwd           {timed(lambda: torch.autograd.grad(re_, (We, be), upe, retain_graph=True)):8.1f} us")
+
+from kvae.vae.fused import EncoderMid
+for side in (16, 8):
+    xm = torch.relu(torch.randn(N, 32, side, side, device=dev)).requires_grad_(True)
+    Wm = (0.08 * torch.randn(32, 32, 3, 3, device=dev)).requires_grad_(True)
+    bm = torch.randn(32, device=dev, requires_grad=True)
+    upm = torch.randn(N, 32, side // 2, side // 2, device=dev)
+    om = EncoderMid.apply(xm, Wm, bm)
+    gmac = N * (side // 2) ** 2 * 32 * 288 / 1e9
+    print(f"enc_mid s={side} ({gmac:.1f} GMAC/pass, MFMA-f32 floor {2 * gmac / 157e3 * 1e6:.0f} us)")
+    print(f"  mfma   fwd            {timed(lambda: EncoderMid.apply(xm, Wm, bm)):8.1f} us")
+    print(f"  mfma   bwd (data+w)   {timed(lambda: torch.autograd.grad(om, (xm, Wm, bm), upm, retain_graph=True)):8.1f} us")
+    print(f"  mfma   bwd (w only)   {timed(lambda: torch.autograd.grad(om, (Wm, bm), upm, retain_graph=True)):8.1f} us")
+    rm = torch.relu(F.conv2d(xm, Wm, bm, stride=2, padding=1))
+    print(f"  miopen fwd+relu       {timed(lambda: torch.relu(F.conv2d(xm, Wm, bm, stride=2, padding=1))):8.1f} us")
+    print(f"  miopen bwd            {timed(lambda: torch.autograd.grad(rm, (xm, Wm, bm), upm, retain_graph=True)):8.1f} us")
