@@ -242,7 +242,7 @@ int64_t kvae_conv_edge_partial_rows(int64_t N);
 int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *out, int64_t N, int32_t C, int32_t side,
                      void *stream);
 /* g_in[N,32,s,s] (may be NULL) = data gradient of g_out * (out > 0); w_partials [rows, 32*32*9] and
- * b_partials [2*rows, 32] with rows = kvae_enc_mid_partial_rows(N, side): gradients are the column sums. */
+ * b_partials [rows, 32] with rows = kvae_enc_mid_partial_rows(N, side): gradients are the column sums. */
 int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const float *g_out, float *g_in,
                      float *w_partials, float *b_partials, int64_t N, int32_t C, int32_t side, void *stream);
 int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side);

@@ -655,12 +655,12 @@ static inline int64_t enc_mid_grid(int64_t N, int32_t side) {
   return iters < 256 ? (iters < 1 ? 1 : iters) : 256;   // one persistent workgroup per CU
 }
 extern "C" {
-int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side) { return enc_mid_grid(N, side) * 4; }
+int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side) { return enc_mid_grid(N, side); }
 
 int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *out, int64_t N, int32_t C, int32_t side,
                      void *stream) {
   if (!in || !W || !bias || !out) return KVAE_ERR_NULL;
-  if (N < 1) return KVAE_ERR_ARG;
+  if (N < 1 || (N + 256 * 8) * EM_C * side * side * 4 >= EM_MAX_BYTES) return KVAE_ERR_ARG;   // 32-bit byte offsets
   if (C != EM_C || (side != 16 && side != 8)) return KVAE_ERR_DIMS;
   const dim3 grid((unsigned)enc_mid_grid(N, side));
   if (side == 16) k_enc_mid_fwd<16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(in, W, bias, out, N);
@@ -670,7 +670,7 @@ int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *
 int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const float *g_out, float *g_in,
                      float *w_partials, float *b_partials, int64_t N, int32_t C, int32_t side, void *stream) {
   if (!in || !W || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
-  if (N < 1) return KVAE_ERR_ARG;
+  if (N < 1 || (N + 256 * 8) * EM_C * side * side * 4 >= EM_MAX_BYTES) return KVAE_ERR_ARG;
   if (C != EM_C || (side != 16 && side != 8)) return KVAE_ERR_DIMS;
   const dim3 grid((unsigned)enc_mid_grid(N, side));
   if (g_in) {

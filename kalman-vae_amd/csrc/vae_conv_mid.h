@@ -38,6 +38,27 @@ __device__ __forceinline__ void em_load_weights(float *Wl, const float *__restri
   }
 }
 
+constexpr int EM_OOB = 1 << 24;   // float index 64 MiB past the start of LDS
+constexpr int64_t EM_MAX_BYTES = (int64_t)1 << 31;   // one launch addresses its tensors with 32-bit byte offsets
+
+// Global traffic goes through raw buffer instructions: out-of-range lanes (the ragged last iteration, the prefetch
+// past the end) load zeros / drop their stores in hardware, so the loops carry no branches around memory operations
+// and hipcc's wait-count insertion can count loads and stores exactly instead of draining vmcnt to 0.
+typedef unsigned int em_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t em_rsrc(const void *p, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 em_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  const em_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void em_st4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const float4 v) {
+  const em_u4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void em_st1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
+}
 #define KV_MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 // row of accumulator register r on this lane half (C/D map of the 32x32 shapes)
 #define KV_ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
@@ -58,49 +79,70 @@ __global__ __launch_bounds__(256) void k_enc_mid_fwd(const float *__restrict__ i
   const int gp = 32 * wv + q, fl = gp / D::PF, pix = gp % D::PF, oh = pix / D::OS, ow = pix % D::OS;
   const bool top = oh == 0, left = ow == 0;
   const int bbase = fl * D::FRAME + half * D::PLANE + (2 * oh - 1) * S + (2 * ow - 1);
+  // Row -1 / column -1 of the padding: those lanes read from far outside the LDS allocation, where DS reads return 0
+  // (a per-MFMA select instead costs 12 % of the kernel).  One base per border case, chosen once.
+  const int b_t = top ? EM_OOB : bbase, b_l = left ? EM_OOB : bbase, b_tl = (top || left) ? EM_OOB : bbase;
   const int abase = half * 32 + q;
   float bv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bv[r] = bias[KV_ACC_ROW(r, half)];
 
+  // Workgroups walk their 64 KiB in 4 KiB pieces starting at different pieces, so that at any instant the CUs are
+  // spread over the memory channels instead of all sitting on the same offset of their chunk.
+  const int rot = blockIdx.x & 15;
+  const __amdgpu_buffer_rsrc_t rin = em_rsrc(in, total * 4), rout = em_rsrc(out, N * EM_C * D::PF * 4);
   float4 pre[16];
   int64_t it = blockIdx.x;
   auto fetch = [&](int64_t i) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int64_t e = i * D::IT_IN + (int64_t)(tid + 256 * j) * 4;
-      pre[j] = e < total ? *reinterpret_cast<const float4 *>(in + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < 16; ++j) pre[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
   };
-  if (it < iters) fetch(it);
+  // An iteration's results are stored at the START of the next one, before its prefetch: the vmcnt wait at the top
+  // of the loop then has only loads younger than the stores, and no store latency lands on the critical path.
+  em_f16 done;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) done[r] = 0.f;
+  uint32_t done_off = 0x80000000u;                      // out of range: nothing to store yet
+  auto flush = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) em_st1(rout, done_off + KV_ACC_ROW(r, half) * D::PF * 4, fmaxf(done[r] + bv[r], 0.f));
+  };
+  fetch(it);
   for (; it < iters; it += gridDim.x) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) reinterpret_cast<float4 *>(fr)[tid + 256 * j] = pre[j];
+    for (int j = 0; j < 16; ++j) reinterpret_cast<float4 *>(fr)[tid + 256 * ((j + rot) & 15)] = pre[j];
     __syncthreads();
-    if (it + gridDim.x < iters) fetch(it + gridDim.x);
+    flush();
+    fetch(it + gridDim.x);                              // past the end: zeros, no branch
     em_f16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // 144 MFMAs as 36 groups of 4; the operands of group g+2 are read while group g is on the matrix core
+    // (sched_barrier keeps hipcc from sinking the reads back next to their use, which exposes the LDS latency).
+    float av[36][4], bw[36][4];
+    auto rd = [&](int g) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
-      const bool zero = (ky == 0 && top) || (kx == 0 && left);
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const float a = Wl[abase + (tap * 32 + 2 * jj) * 32];
-        float b = fr[bbase + ky * S + kx + 2 * jj * D::PLANE];
-        b = zero ? 0.f : b;
-        acc = KV_MFMA_F32(a, b, acc);
+      for (int u = 0; u < 4; ++u) {
+        const int k = g * 4 + u, tap = k / 16, jj = k % 16, ky = tap / 3, kx = tap % 3;
+        av[g][u] = Wl[abase + (tap * 32 + 2 * jj) * 32];
+        bw[g][u] = fr[(ky == 0 ? (kx == 0 ? b_tl : b_t) : (kx == 0 ? b_l : bbase)) + ky * S + kx + 2 * jj * D::PLANE];
       }
-    }
-    const int64_t frame = it * D::FPI + fl;
-    if (frame < N) {
-      float *o = out + frame * EM_C * D::PF + pix;
+    };
+    rd(0);
+    rd(1);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[KV_ACC_ROW(r, half) * D::PF] = fmaxf(acc[r] + bv[r], 0.f);
+    for (int g = 0; g < 36; ++g) {
+      if (g + 2 < 36) rd(g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = KV_MFMA_F32(av[g][u], bw[g][u], acc);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    done = acc;
+    done_off = (uint32_t)((it * D::FPI + fl) * EM_C * D::PF + pix) * 4u;   // frames >= N: dropped by the hardware
   }
+  flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -122,71 +164,88 @@ __global__ __launch_bounds__(256) void k_enc_mid_bwd_data(const float *__restric
   const int cp = 32 * wv + q, fl = cp / D::PF, idx = cp % D::PF, a_ = idx / D::OS, b_ = idx % D::OS;
   const bool bottom = a_ == D::OS - 1, right = b_ == D::OS - 1;
   const int gbase = fl * EM_C * D::PF + half * D::PF + a_ * D::OS + b_;
+  const int g_b = bottom ? EM_OOB : gbase, g_r = right ? EM_OOB : gbase, g_br = (bottom || right) ? EM_OOB : gbase;
   const int abase = half * 32 + q;
   const int obase = fl * D::FRAME + (2 * a_) * S + 2 * b_;
 
+  const int rot = blockIdx.x & 15;
+  const __amdgpu_buffer_rsrc_t rg = em_rsrc(g_out, total_out * 4), ro = em_rsrc(out, total_out * 4),
+                               rgi = em_rsrc(g_in, total_in * 4);
   float4 pg[4], po[4];
   int64_t it = blockIdx.x;
   auto fetch = [&](int64_t i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t e = i * D::IT_OUT + (int64_t)(tid + 256 * j) * 4;
-      const bool ok = e < total_out;
-      pg[j] = ok ? *reinterpret_cast<const float4 *>(g_out + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      po[j] = ok ? *reinterpret_cast<const float4 *>(out + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * ((j + rot) & 3)) * 4) * 4u;
+      pg[j] = em_ld4(rg, e);
+      po[j] = em_ld4(ro, e);
     }
   };
-  if (it < iters) fetch(it);
-  for (; it < iters; it += gridDim.x) {
-    __syncthreads();                                   // previous iteration's LDS images fully consumed
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      reinterpret_cast<float4 *>(gm)[tid + 256 * j] = make_float4(po[j].x > 0.f ? pg[j].x : 0.f, po[j].y > 0.f ? pg[j].y : 0.f,
-                                                                   po[j].z > 0.f ? pg[j].z : 0.f, po[j].w > 0.f ? pg[j].w : 0.f);
-    __syncthreads();
-    if (it + gridDim.x < iters) fetch(it + gridDim.x);
-#pragma unroll
-    for (int cls = 0; cls < 4; ++cls) {
-      const int ph = cls >> 1, pw = cls & 1;
-      em_f16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        if ((ky & 1) == ph) continue;                  // row parity: even rows take ky = 1, odd rows ky = 0 and 2
-        const int dy = (ph == 1 && ky == 0) ? 1 : 0;   // oh = a + dy
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          if ((kx & 1) == pw) continue;
-          const int dx = (pw == 1 && kx == 0) ? 1 : 0;
-          const int tap = ky * 3 + kx;
-          const bool zero = (dy == 1 && bottom) || (dx == 1 && right);
-#pragma unroll
-          for (int jj = 0; jj < 16; ++jj) {
-            const float a = Wl[abase + (tap * 32 + 2 * jj) * 32];
-            float b = gm[gbase + 2 * jj * D::PF + dy * D::OS + dx];
-            b = zero ? 0.f : b;
-            acc = KV_MFMA_F32(a, b, acc);
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[obase + KV_ACC_ROW(r, half) * D::PLANE + ph * S + pw] = acc[r];
-    }
-    __syncthreads();
+  uint32_t done_base = 0x80000000u;                     // out of range until an image exists
+  auto flush = [&]() {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int64_t e = it * D::IT_IN + (int64_t)(tid + 256 * j) * 4;
-      if (e < total_in) *reinterpret_cast<float4 *>(g_in + e) = reinterpret_cast<const float4 *>(ot)[tid + 256 * j];
+      const int c = (j + rot) & 15;
+      em_st4(rgi, done_base + (uint32_t)(tid + 256 * c) * 16u, reinterpret_cast<const float4 *>(ot)[tid + 256 * c]);
     }
+  };
+  fetch(it);
+  for (; it < iters; it += gridDim.x) {
+    __syncthreads();                                   // previous iteration's gm consumed, its ot complete
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      reinterpret_cast<float4 *>(gm)[tid + 256 * ((j + rot) & 3)] =
+          make_float4(po[j].x > 0.f ? pg[j].x : 0.f, po[j].y > 0.f ? pg[j].y : 0.f, po[j].z > 0.f ? pg[j].z : 0.f,
+                      po[j].w > 0.f ? pg[j].w : 0.f);
+    flush();                                           // previous iteration's image, before this one's prefetch
+    __syncthreads();                                   // gm visible; ot read out before the classes overwrite it
+    fetch(it + gridDim.x);
+    // nine (class, tap) entries in class order, 16 MFMAs each, run as 36 groups of 4 with the operands of group g+2
+    // in flight while group g is on the matrix core
+    constexpr int E_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+    constexpr int E_KY[9] = {1, 1, 1, 0, 2, 0, 0, 2, 2};
+    constexpr int E_KX[9] = {1, 0, 2, 1, 1, 0, 2, 0, 2};
+    float av[36][4], bw[36][4];
+    auto rd = [&](int g) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int en = g / 4, jj = (g % 4) * 4 + u, ph = E_CLS[en] >> 1, pw = E_CLS[en] & 1;
+        const int dy = (ph == 1 && E_KY[en] == 0) ? 1 : 0, dx = (pw == 1 && E_KX[en] == 0) ? 1 : 0;   // oh = a + dy
+        av[g][u] = Wl[abase + ((E_KY[en] * 3 + E_KX[en]) * 32 + 2 * jj) * 32];
+        bw[g][u] = gm[(dy ? (dx ? g_br : g_b) : (dx ? g_r : gbase)) + 2 * jj * D::PF + dy * D::OS + dx];
+      }
+    };
+    rd(0);
+    rd(1);
+    em_f16 acc;
+#pragma unroll
+    for (int g = 0; g < 36; ++g) {
+      const int en = g / 4, cls = E_CLS[en], ph = cls >> 1, pw = cls & 1;
+      if (g % 4 == 0 && (en == 0 || E_CLS[en - 1] != cls)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
+      if (g + 2 < 36) rd(g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = KV_MFMA_F32(av[g][u], bw[g][u], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g % 4 == 3 && (en == 8 || E_CLS[en + 1] != cls)) {   // class complete: rows ci, column = this lane's pixel
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[obase + KV_ACC_ROW(r, half) * D::PLANE + ph * S + pw] = acc[r];
+      }
+    }
+    done_base = (uint32_t)(it * D::IT_IN) * 4u;
   }
+  __syncthreads();
+  flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient: dW[co,ci,tap] = sum_{n,oh,ow} gm[n,co,oh,ow] in[n,ci,2oh+ky-1,2ow+kx-1]; db[co] = sum gm.
 // GEMM view: nine 32 x 32 tiles D_tap[co][ci] += A[co][pixel] B_tap[pixel][ci], 819k pixels deep.  The 64 pixel pairs
 // of an iteration are split over the four waves (16 each, x 9 taps = 144 MFMAs); every wave keeps its own nine tiles
-// in 144 accumulator registers for the whole kernel and writes them out once as a partial row.
+// in 144 accumulator registers for the whole kernel; at the end the workgroup folds them into one partial row.
 // Channel planes are padded by one float in LDS so that 32 lanes on 32 channels hit 32 banks.
 // ---------------------------------------------------------------------------------------------------------------
 template <int S>
@@ -204,6 +263,10 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
   const int oh0 = wpix0 / D::OS;
   const int abase = wframe * EM_C * GSP + q * GSP + wpix0 + half;
   const int bbase = wframe * EM_C * CSP + q * CSP + (2 * oh0 - 1) * S - 1 + 2 * half;
+  // row -1 (first pixel row of the frame, wave-uniform) and column -1 (first pixel of a pair at column 0): read zeros
+  // from outside the LDS allocation instead of selecting per MFMA
+  const bool wtop = oh0 == 0, wleft = half == 0;
+  const int x_t = wtop ? EM_OOB : bbase, x_l = wleft ? EM_OOB : bbase, x_tl = (wtop || wleft) ? EM_OOB : bbase;
 
   em_f16 acc[9];
 #pragma unroll
@@ -212,65 +275,83 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
+  const int rot = blockIdx.x & 15;
+  const __amdgpu_buffer_rsrc_t rin = em_rsrc(in, total_in * 4), rg = em_rsrc(g_out, total_out * 4),
+                               ro = em_rsrc(out, total_out * 4);
   float4 px[16], pg[4], po[4];
   int64_t it = blockIdx.x;
   auto fetch = [&](int64_t i) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int64_t e = i * D::IT_IN + (int64_t)(tid + 256 * j) * 4;
-      px[j] = e < total_in ? *reinterpret_cast<const float4 *>(in + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < 16; ++j) px[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t e = i * D::IT_OUT + (int64_t)(tid + 256 * j) * 4;
-      const bool ok = e < total_out;
-      pg[j] = ok ? *reinterpret_cast<const float4 *>(g_out + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      po[j] = ok ? *reinterpret_cast<const float4 *>(out + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * ((j + rot) & 3)) * 4) * 4u;
+      pg[j] = em_ld4(rg, e);
+      po[j] = em_ld4(ro, e);
     }
   };
-  if (it < iters) fetch(it);
+  fetch(it);
   for (; it < iters; it += gridDim.x) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int e = (tid + 256 * j) * 4, f = e / D::FRAME, c = (e % D::FRAME) / D::PLANE, p = e % D::PLANE;
+      const int e = (tid + 256 * ((j + rot) & 15)) * 4, f = e / D::FRAME, c = (e % D::FRAME) / D::PLANE, p = e % D::PLANE;
       float *d = xin + (f * EM_C + c) * CSP + p;
       d[0] = px[j].x; d[1] = px[j].y; d[2] = px[j].z; d[3] = px[j].w;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int e = (tid + 256 * j) * 4, f = e / (EM_C * D::PF), c = (e / D::PF) % EM_C, p = e % D::PF;
+      const int e = (tid + 256 * ((j + rot) & 3)) * 4, f = e / (EM_C * D::PF), c = (e / D::PF) % EM_C, p = e % D::PF;
       float *d = gm + (f * EM_C + c) * GSP + p;
       d[0] = po[j].x > 0.f ? pg[j].x : 0.f; d[1] = po[j].y > 0.f ? pg[j].y : 0.f;
       d[2] = po[j].z > 0.f ? pg[j].z : 0.f; d[3] = po[j].w > 0.f ? pg[j].w : 0.f;
     }
     __syncthreads();
-    if (it + gridDim.x < iters) fetch(it + gridDim.x);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      // pixel pair i of this wave: frame offset fi, first pixel p (even) relative to wpix0
+    fetch(it + gridDim.x);
+    // pixel pair i of this wave: frame offset fi, first pixel p (even) relative to wpix0; the ten operands of pair
+    // i+1 are read while the nine MFMAs of pair i run
+    float av[16], bw[16][9];
+    auto rd = [&](int i) {
       const int fi = S == 16 ? 0 : i / 8, p = S == 16 ? 2 * i : 2 * (i % 8);
       const int ohr = p / D::OS, owr = p % D::OS;          // relative row, column of the pair's first pixel
-      const float a = gm[abase + fi * EM_C * GSP + p];
-      bsum += a;
-      const bool ztop = (oh0 + ohr) == 0;                   // wave-uniform
+      av[i] = gm[abase + fi * EM_C * GSP + p];
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        float b = xin[bbase + fi * EM_C * CSP + (2 * ohr + ky) * S + 2 * owr + kx];
-        if (ky == 0) b = ztop ? 0.f : b;
-        if (kx == 0 && owr == 0) b = half == 0 ? 0.f : b;   // column -1 belongs to the pair's first pixel only
-        acc[tap] = KV_MFMA_F32(a, b, acc[tap]);
+        const bool zt = tap / 3 == 0 && ohr == 0, zl = tap % 3 == 0 && owr == 0;
+        bw[i][tap] = xin[(zt ? (zl ? x_tl : x_t) : (zl ? x_l : bbase)) + fi * EM_C * CSP + (2 * ohr + tap / 3) * S + 2 * owr + tap % 3];
       }
+    };
+    rd(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i + 1 < 16) rd(i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += av[i];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) acc[tap] = KV_MFMA_F32(av[i], bw[i][tap], acc[tap]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // D_tap[co][ci]: column ci = q on the lane, rows co in the registers
-  float *wp = w_partials + (int64_t)(blockIdx.x * 4 + wv) * EM_W;
+  // D_tap[co][ci]: column ci = q on the lane, rows co in the registers.  The four waves fold their tiles through LDS
+  // (one after the other) so that a workgroup emits ONE partial row, written coalesced.
+  float *red = lds, *redb = lds + EM_W;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wv == w) {
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+      for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wp[(KV_ACC_ROW(r, half) * EM_C + q) * 9 + tap] = acc[tap][r];
-  b_partials[(int64_t)((blockIdx.x * 4 + wv) * 2 + half) * EM_C + q] = bsum;
+        for (int r = 0; r < 16; ++r) {
+          float *d = red + (KV_ACC_ROW(r, half) * EM_C + q) * 9 + tap;
+          *d = w == 0 ? acc[tap][r] : *d + acc[tap][r];
+        }
+      float *db = redb + half * EM_C + q;
+      *db = w == 0 ? bsum : *db + bsum;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < EM_W; i += 256) w_partials[(int64_t)blockIdx.x * EM_W + i] = red[i];
+  if (tid < EM_C) b_partials[(int64_t)blockIdx.x * EM_C + tid] = redb[tid] + redb[EM_C + tid];
 }
 
 }  // namespace kvae

@@ -153,7 +153,7 @@ class EncoderMid(torch.autograd.Function):
         rows = lib.dll.kvae_enc_mid_partial_rows(Nb, s)
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
-        bp = torch.empty(2 * rows, Cc, device=x.device, dtype=torch.float32)
+        bp = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
                                            N.ptr(wp), N.ptr(bp), Nb, Cc, s, N.stream_for(x)), "kvae_enc_mid_bwd")
         return g_x, wp.sum(0).view_as(weight), bp.sum(0)

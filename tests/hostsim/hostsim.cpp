@@ -415,7 +415,7 @@ static int64_t enc_mid_grid_sim(int64_t N, int32_t side) {
   const int64_t fpi = side == 16 ? 2 : 8, iters = (N + fpi - 1) / fpi;
   return iters < 256 ? (iters < 1 ? 1 : iters) : 256;
 }
-int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side) { return enc_mid_grid_sim(N, side) * 4; }
+int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side) { return enc_mid_grid_sim(N, side); }
 
 int kvae_enc_mid_fwd(const float *in, const float *W, const float *bias, float *out, int64_t N, int32_t C, int32_t side,
                      void *) {
@@ -447,10 +447,10 @@ int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const fl
   const int S = side, O = side / 2;
   const int64_t rows = kvae_enc_mid_partial_rows(N, side);
   memset(w_partials, 0, sizeof(float) * rows * C * C * 9);
-  memset(b_partials, 0, sizeof(float) * 2 * rows * C);
+  memset(b_partials, 0, sizeof(float) * rows * C);
   if (g_in) memset(g_in, 0, sizeof(float) * N * C * S * S);
   for (int64_t n = 0; n < N; ++n) {
-    float *wp = w_partials + (n % rows) * C * C * 9, *bp = b_partials + (n % (2 * rows)) * C;
+    float *wp = w_partials + (n % rows) * C * C * 9, *bp = b_partials + (n % rows) * C;
     for (int co = 0; co < C; ++co)
       for (int oh = 0; oh < O; ++oh)
         for (int ow = 0; ow < O; ++ow) {
