@@ -206,6 +206,8 @@ int kvae_bias_shuffle_act_fwd(const float *in, const float *bias, float *out, in
 int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in, float *bias_partials, int64_t N,
                               int32_t C, int32_t H, int32_t W, int32_t r, int32_t relu, void *stream);
 int64_t kvae_bias_partial_rows(int64_t N);
+/* out[c] = sum_r partials[r, c]: the second stage of the partial-row reductions above and below. */
+int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, void *stream);
 
 /* ---- fused Bernoulli reconstruction term of the frame VAE --------------------------------- */
 

@@ -345,6 +345,27 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
 // ---------------------------------------------------------------------------------------------
 #include "vae_epilogue.h"
 
+// out[c] = sum_r partials[r, c]: second stage of every deterministic two-stage reduction of the VAE kernels (bias and
+// weight gradient partial rows).  64 columns x 4 row lanes per block: coalesced along c, rows folded through LDS.
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partials, float *__restrict__ out, int64_t rows,
+                                                int64_t cols) {
+  __shared__ float red[256];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int64_t r = ry;
+    for (; r + 4 < rows; r += 8) {
+      s0 += partials[r * cols + c];
+      s1 += partials[(r + 4) * cols + c];
+    }
+    if (r < rows) s0 += partials[r * cols + c];
+  }
+  red[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && c < cols) out[c] = (red[cx] + red[64 + cx]) + (red[128 + cx] + red[192 + cx]);
+}
+
 // Forward, R = 1 or 2: each thread produces 4 consecutive outputs along W (one 16-byte store) from one 16-byte
 // (R = 1) or two 8-byte (R = 2: the two sub-pixel channels dx = 0,1 of this output row) loads; 32-bit index math.
 template <int R>
@@ -469,6 +490,12 @@ int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in,
   }
   k_vae_epilogue_bwd<<<dim3(epi_grid(total)), dim3(256), 0, st>>>(g_out, out, g_in, s, total, relu);
   return launch_status("k_vae_epilogue_bwd");
+}
+int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, void *stream) {
+  if (!partials || !out) return KVAE_ERR_NULL;
+  if (rows < 1 || cols < 1) return KVAE_ERR_ARG;
+  k_colsum<<<dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(partials, out, rows, cols);
+  return launch_status("k_colsum");
 }
 int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHUNK - 1) / KVAE_EPI_SAMPLES_PER_CHUNK; }
 }  // extern "C"

@@ -59,6 +59,12 @@ __device__ __forceinline__ void em_st4(__amdgpu_buffer_rsrc_t r, uint32_t byte_o
 __device__ __forceinline__ void em_st1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 0);
 }
+#ifdef KVAE_EM_STAMPS   // tools/em_stamp.hip only: per-phase s_memtime stamps of workgroup 0, thread 0
+__device__ unsigned long long em_stamps[4096];
+#define EM_STAMP(slot, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 500) em_stamps[(slot) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EM_STAMP(slot, k) do {} while (0)
+#endif
 #define KV_MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 // row of accumulator register r on this lane half (C/D map of the 32x32 shapes)
 #define KV_ACC_ROW(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
@@ -71,8 +77,8 @@ template <int S>
 __global__ __launch_bounds__(256) void k_enc_mid_fwd(const float *__restrict__ in, const float *__restrict__ W,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t N) {
   using D = EmDims<S>;
-  __shared__ float lds[EM_W + D::IT_IN];
-  float *Wl = lds, *fr = lds + EM_W;
+  __shared__ float lds[EM_W + D::IT_IN + D::IT_OUT];
+  float *Wl = lds, *fr = lds + EM_W, *ot = fr + D::IT_IN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane & 31, half = lane >> 5;
   em_load_weights(Wl, W, true);
   const int64_t iters = (N + D::FPI - 1) / D::FPI, total = N * D::FRAME;
@@ -93,28 +99,33 @@ __global__ __launch_bounds__(256) void k_enc_mid_fwd(const float *__restrict__ i
   const __amdgpu_buffer_rsrc_t rin = em_rsrc(in, total * 4), rout = em_rsrc(out, N * EM_C * D::PF * 4);
   float4 pre[16];
   int64_t it = blockIdx.x;
-  auto fetch = [&](int64_t i) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) pre[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
+  auto fetch1 = [&](int64_t i, int j) {
+    pre[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
   };
-  // An iteration's results are stored at the START of the next one, before its prefetch: the vmcnt wait at the top
-  // of the loop then has only loads younger than the stores, and no store latency lands on the critical path.
-  em_f16 done;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) done[r] = 0.f;
-  uint32_t done_off = 0x80000000u;                      // out of range: nothing to store yet
-  auto flush = [&]() {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) em_st1(rout, done_off + KV_ACC_ROW(r, half) * D::PF * 4, fmaxf(done[r] + bv[r], 0.f));
+  // An iteration's 16 KiB of results go through an LDS image (same layout as the global chunk) and leave as four
+  // dwordx4 stores per thread at the START of the next iteration, before its prefetch: 16 scattered dword stores per
+  // lane are store-issue-bound (~1.3 us per iteration), and stores issued right before the loop-top wait would put
+  // their latency on the critical path.
+  // Vector-memory instructions are NOT fire-and-forget for the issuing wave: 16 dwordx4 loads issued back to back
+  // hold it for ~3000 cycles (measured with s_memtime; the CU's memory pipeline takes them at ~21 B/clk), and with one
+  // wave per SIMD the matrix core idles meanwhile.  So the 4 stores and 16 loads of an iteration are dealt out one per
+  // MFMA group (every 256 cycles) instead.
+  uint32_t done_base = 0x80000000u;                     // out of range: nothing to store yet
+  auto flush1 = [&](int j) {
+    em_st4(rout, done_base + (uint32_t)(tid + 256 * j) * 16u, reinterpret_cast<const float4 *>(ot)[tid + 256 * j]);
   };
-  fetch(it);
-  for (; it < iters; it += gridDim.x) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) fetch1(it, j);
+  for (int slot = 0; it < iters; it += gridDim.x, ++slot) {
+    EM_STAMP(slot, 0);
     __syncthreads();
+    EM_STAMP(slot, 1);
 #pragma unroll
     for (int j = 0; j < 16; ++j) reinterpret_cast<float4 *>(fr)[tid + 256 * ((j + rot) & 15)] = pre[j];
+    EM_STAMP(slot, 2);
     __syncthreads();
-    flush();
-    fetch(it + gridDim.x);                              // past the end: zeros, no branch
+    EM_STAMP(slot, 3);
+    EM_STAMP(slot, 4);
     em_f16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -134,15 +145,24 @@ __global__ __launch_bounds__(256) void k_enc_mid_fwd(const float *__restrict__ i
 #pragma unroll
     for (int g = 0; g < 36; ++g) {
       if (g + 2 < 36) rd(g + 2);
+      if (g < 4) flush1(g);                             // previous image out first (oldest in the vmcnt order)
+      else if (g < 20) fetch1(it + gridDim.x, g - 4);   // past the end: zeros, no branch
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = KV_MFMA_F32(av[g][u], bw[g][u], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
-    done = acc;
-    done_off = (uint32_t)((it * D::FPI + fl) * EM_C * D::PF + pix) * 4u;   // frames >= N: dropped by the hardware
+    EM_STAMP(slot, 5);
+    __syncthreads();                                    // every wave has read the previous image out (flush above)
+    EM_STAMP(slot, 6);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[(fl * EM_C + KV_ACC_ROW(r, half)) * D::PF + pix] = fmaxf(acc[r] + bv[r], 0.f);
+    EM_STAMP(slot, 7);
+    done_base = (uint32_t)(it * D::IT_OUT) * 4u;        // frames >= N: dropped by the hardware
   }
-  flush();
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) flush1(j);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -173,23 +193,21 @@ __global__ __launch_bounds__(256) void k_enc_mid_bwd_data(const float *__restric
                                rgi = em_rsrc(g_in, total_in * 4);
   float4 pg[4], po[4];
   int64_t it = blockIdx.x;
-  auto fetch = [&](int64_t i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * ((j + rot) & 3)) * 4) * 4u;
-      pg[j] = em_ld4(rg, e);
-      po[j] = em_ld4(ro, e);
-    }
+  auto fetch1 = [&](int64_t i, int j) {                 // j < 8: g_out pieces 0..3, then out pieces 0..3
+    const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * (((j & 3) + rot) & 3)) * 4) * 4u;
+    if (j < 4) pg[j] = em_ld4(rg, e);
+    else po[j - 4] = em_ld4(ro, e);
   };
+  // The image of iteration i leaves during iteration i+1: its 16 stores and the 8 prefetch loads are dealt out one per
+  // MFMA group (see the forward kernel).  The deepest class (4 taps, 16 groups) runs first so that all 16 stores have
+  // read the old image before the first class result is written into it.
   uint32_t done_base = 0x80000000u;                     // out of range until an image exists
-  auto flush = [&]() {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int c = (j + rot) & 15;
-      em_st4(rgi, done_base + (uint32_t)(tid + 256 * c) * 16u, reinterpret_cast<const float4 *>(ot)[tid + 256 * c]);
-    }
+  auto flush1 = [&](int j) {
+    const int c = (j + rot) & 15;
+    em_st4(rgi, done_base + (uint32_t)(tid + 256 * c) * 16u, reinterpret_cast<const float4 *>(ot)[tid + 256 * c]);
   };
-  fetch(it);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) fetch1(it, j);
   for (; it < iters; it += gridDim.x) {
     __syncthreads();                                   // previous iteration's gm consumed, its ot complete
 #pragma unroll
@@ -197,14 +215,12 @@ __global__ __launch_bounds__(256) void k_enc_mid_bwd_data(const float *__restric
       reinterpret_cast<float4 *>(gm)[tid + 256 * ((j + rot) & 3)] =
           make_float4(po[j].x > 0.f ? pg[j].x : 0.f, po[j].y > 0.f ? pg[j].y : 0.f, po[j].z > 0.f ? pg[j].z : 0.f,
                       po[j].w > 0.f ? pg[j].w : 0.f);
-    flush();                                           // previous iteration's image, before this one's prefetch
-    __syncthreads();                                   // gm visible; ot read out before the classes overwrite it
-    fetch(it + gridDim.x);
-    // nine (class, tap) entries in class order, 16 MFMAs each, run as 36 groups of 4 with the operands of group g+2
-    // in flight while group g is on the matrix core
-    constexpr int E_CLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
-    constexpr int E_KY[9] = {1, 1, 1, 0, 2, 0, 0, 2, 2};
-    constexpr int E_KX[9] = {1, 0, 2, 1, 1, 0, 2, 0, 2};
+    __syncthreads();                                   // gm visible
+    // nine (class, tap) entries, deepest class first, 16 MFMAs each, run as 36 groups of 4 with the operands of group
+    // g+2 in flight while group g is on the matrix core
+    constexpr int E_CLS[9] = {3, 3, 3, 3, 1, 1, 2, 2, 0};
+    constexpr int E_KY[9] = {0, 0, 2, 2, 1, 1, 0, 2, 1};
+    constexpr int E_KX[9] = {0, 2, 0, 2, 0, 2, 1, 1, 1};
     float av[36][4], bw[36][4];
     auto rd = [&](int g) {
 #pragma unroll
@@ -226,11 +242,14 @@ __global__ __launch_bounds__(256) void k_enc_mid_bwd_data(const float *__restric
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       }
       if (g + 2 < 36) rd(g + 2);
+      if (g < 16) flush1(g);                            // old image out (oldest in the vmcnt order)
+      else if (g < 24) fetch1(it + gridDim.x, g - 16);  // past the end: zeros, no branch
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = KV_MFMA_F32(av[g][u], bw[g][u], acc);
       __builtin_amdgcn_sched_barrier(0);
       if (g % 4 == 3 && (en == 8 || E_CLS[en + 1] != cls)) {   // class complete: rows ci, column = this lane's pixel
+        if (g == 15) __syncthreads();                   // every wave has read the old image (16 flushes) before it changes
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[obase + KV_ACC_ROW(r, half) * D::PLANE + ph * S + pw] = acc[r];
       }
@@ -238,7 +257,8 @@ __global__ __launch_bounds__(256) void k_enc_mid_bwd_data(const float *__restric
     done_base = (uint32_t)(it * D::IT_IN) * 4u;
   }
   __syncthreads();
-  flush();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) flush1(j);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -280,17 +300,17 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
                                ro = em_rsrc(out, total_out * 4);
   float4 px[16], pg[4], po[4];
   int64_t it = blockIdx.x;
-  auto fetch = [&](int64_t i) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) px[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * ((j + rot) & 3)) * 4) * 4u;
-      pg[j] = em_ld4(rg, e);
-      po[j] = em_ld4(ro, e);
+  auto fetch1 = [&](int64_t i, int j) {                 // 24 pieces: 16 of in, 4 of g_out, 4 of out
+    if (j < 16) {
+      px[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
+    } else {
+      const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * (((j & 3) + rot) & 3)) * 4) * 4u;
+      if (j < 20) pg[j - 16] = em_ld4(rg, e);
+      else po[j - 20] = em_ld4(ro, e);
     }
   };
-  fetch(it);
+#pragma unroll
+  for (int j = 0; j < 24; ++j) fetch1(it, j);
   for (; it < iters; it += gridDim.x) {
     __syncthreads();
 #pragma unroll
@@ -307,7 +327,6 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
       d[2] = po[j].z > 0.f ? pg[j].z : 0.f; d[3] = po[j].w > 0.f ? pg[j].w : 0.f;
     }
     __syncthreads();
-    fetch(it + gridDim.x);
     // pixel pair i of this wave: frame offset fi, first pixel p (even) relative to wpix0; the ten operands of pair
     // i+1 are read while the nine MFMAs of pair i run
     float av[16], bw[16][9];
@@ -325,6 +344,10 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if (i + 1 < 16) rd(i + 1);
+      if (i < 12) {                                       // the next iteration's 24 loads, two per group (see forward)
+        fetch1(it + gridDim.x, 2 * i);
+        fetch1(it + gridDim.x, 2 * i + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       bsum += av[i];
 #pragma unroll

@@ -47,7 +47,7 @@ class InputGrads(C.Structure):  # kvae_lgssm_input_grads
 
 SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
            "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_lstm_fwd",
-           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
+           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
            "kvae_abi_version",
@@ -116,6 +116,8 @@ class LgssmLib:
         d.kvae_enc_mid_partial_rows.restype = C.c_int64
         d.kvae_conv_edge_partial_rows.argtypes = [C.c_int64]
         d.kvae_conv_edge_partial_rows.restype = C.c_int64
+        d.kvae_colsum.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
+        d.kvae_colsum.restype = C.c_int
         d.kvae_bias_partial_rows.argtypes = [C.c_int64]
         d.kvae_bias_partial_rows.restype = C.c_int64
         d.kvae_abi_version.restype = C.c_int
@@ -207,3 +209,14 @@ def timed(name, t, thunk):
     e.record()
     _prof.setdefault(name, []).append((s, e))
     return rc
+
+
+def colsum(partials):
+    """out[c] = sum_r partials[r, c] in one small kernel (k_colsum): the second stage of every partial-row reduction.
+    torch's sum(0) on these shapes costs ~18 us per call and there are ~20 of them per training step."""
+    import torch
+    p2 = partials.reshape(partials.shape[0], -1).contiguous()
+    out = torch.empty(p2.shape[1], device=p2.device, dtype=torch.float32)
+    lib = lib_for(p2)
+    lib.check(lib.dll.kvae_colsum(ptr(p2), ptr(out), p2.shape[0], p2.shape[1], stream_for(p2)), "kvae_colsum")
+    return out.view(partials.shape[1:])

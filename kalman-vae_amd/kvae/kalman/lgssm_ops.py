@@ -178,9 +178,9 @@ class LgssmSmooth(torch.autograd.Function):
             C.byref(call.prob), C.byref(saved), C.byref(up), C.byref(sink.g), N.ptr(ws), int(with_rts), call.stream)),
             "kvae_lgssm_smooth_bwd")
         if g0 is not None and mu0.dim() == 1:
-            g0 = g0.sum(0)
+            g0 = N.colsum(g0)
         if S0 is not None and Sigma0.dim() == 2:
-            S0 = S0.sum(0)
+            S0 = N.colsum(S0)
         return (sink.gY if need[0] else None, sink.gU if need[1] else None, None, sink.gpacked,
                 sink.operand_grad("gA"), sink.operand_grad("gB"), sink.operand_grad("gC"),
                 sink.operand_grad("gQ") if need_q else None, None, g0, S0, None, None)
@@ -315,7 +315,7 @@ class LstmSequence(torch.autograd.Function):
         h_prev = torch.cat([h.new_zeros(Bsz, 1, H), h[:, :-1]], dim=1).reshape(Bsz * T, H)
         g_whh = d2.t() @ h_prev
         g_wih = d2.t() @ x.reshape(Bsz * T, I)
-        g_b = d2.sum(0)
+        g_b = N.colsum(d2)
         return dx, g_wih, g_whh, g_b, g_b
 
 
@@ -399,7 +399,7 @@ class BiGruSequence(torch.autograd.Function):
         out = [dx.sum(0)]
         for d in (0, 1):
             di, dh = dpi[d].reshape(Bsz * T, 3 * H), dph[d].reshape(Bsz * T, 3 * H)
-            out += [di.t() @ x2, dh.t() @ hp[d].reshape(Bsz * T, H), di.sum(0), dh.sum(0)]
+            out += [di.t() @ x2, dh.t() @ hp[d].reshape(Bsz * T, H), N.colsum(di), N.colsum(dh)]
         return tuple(out)
 
 

@@ -8,6 +8,9 @@ import torch
 from .. import _native as N
 
 
+colsum = N.colsum
+
+
 class BiasShuffleAct(torch.autograd.Function):
     """out[N,C,H*r,W*r] = act(pixel_shuffle_r(x[N,C*r*r,H,W] + bias))."""
 
@@ -35,7 +38,7 @@ class BiasShuffleAct(torch.autograd.Function):
         partials = torch.empty(lib.dll.kvae_bias_partial_rows(Nb), C * ctx.r * ctx.r, device=g.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_bias_shuffle_act_bwd(N.ptr(g), N.ptr(out), N.ptr(g_in), N.ptr(partials), Nb, C, H, W, ctx.r,
                                                     int(ctx.relu), N.stream_for(g)), "kvae_bias_shuffle_act_bwd")
-        return g_in, partials.sum(0), None, None
+        return g_in, colsum(partials), None, None
 
 
 def conv_block(x, conv, r=1, relu=True):
@@ -83,7 +86,7 @@ class DecoderHead(torch.autograd.Function):
         lib.check(lib.dll.kvae_dec_head_bwd(N.ptr(h), N.ptr(weight), N.ptr(g), N.ptr(g_h) if g_h is not None else None,
                                             N.ptr(wp), N.ptr(bp), N.ptr(scratch), Nb, Cin, s, N.stream_for(h)),
                   "kvae_dec_head_bwd")
-        return g_h, wp.sum(0).view_as(weight), bp.sum(0)
+        return g_h, colsum(wp).view_as(weight), colsum(bp)
 
 
 class EncoderStem(torch.autograd.Function):
@@ -120,7 +123,7 @@ class EncoderStem(torch.autograd.Function):
         bp = torch.empty(rows, Cout, device=x.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(g), N.ptr(wp), N.ptr(bp), Nb, Cout, x.shape[2],
                                             N.stream_for(x)), "kvae_enc_stem_bwd")
-        return None, wp.sum(0).view(ctx.wshape), bp.sum(0)
+        return None, colsum(wp).view(ctx.wshape), colsum(bp)
 
 
 class EncoderMid(torch.autograd.Function):
@@ -156,7 +159,7 @@ class EncoderMid(torch.autograd.Function):
         bp = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
                                            N.ptr(wp), N.ptr(bp), Nb, Cc, s, N.stream_for(x)), "kvae_enc_mid_bwd")
-        return g_x, wp.sum(0).view_as(weight), bp.sum(0)
+        return g_x, colsum(wp).view_as(weight), colsum(bp)
 
 
 class BernoulliFrameLogLik(torch.autograd.Function):

@@ -217,6 +217,16 @@ int kvae_bias_shuffle_act_fwd(const float *in, const float *bias, float *out, in
   return KVAE_OK;
 }
 int64_t kvae_bias_partial_rows(int64_t N) { return (N + 31) / 32; }
+int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, void *) {
+  if (!partials || !out) return KVAE_ERR_NULL;
+  if (rows < 1 || cols < 1) return KVAE_ERR_ARG;
+  for (int64_t c = 0; c < cols; ++c) {
+    float s = 0.f;
+    for (int64_t r = 0; r < rows; ++r) s += partials[r * cols + c];
+    out[c] = s;
+  }
+  return KVAE_OK;
+}
 int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in, float *bias_partials, int64_t N, int32_t C,
                               int32_t H, int32_t W, int32_t r, int32_t relu, void *) {
   if (!g_out || !g_in || (relu && !out)) return KVAE_ERR_NULL;
