@@ -249,6 +249,17 @@ int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const fl
                      float *w_partials, float *b_partials, int64_t N, int32_t C, int32_t side, void *stream);
 int64_t kvae_enc_mid_partial_rows(int64_t N, int32_t side);
 
+/* Decoder up-sampling blocks (kvae/vae/vae.py:92-101):
+ * out[N,32,2s,2s] = relu(pixel_shuffle_2(conv3x3_pad1(x[N,32,s,s], W[128,32,3,3]) + b[128])) on the f32 matrix cores,
+ * weights stationary in registers.  Built for Cin = 32 and s in {8, 4}; other shapes return KVAE_ERR_DIMS. */
+int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cin, int32_t side,
+                    void *stream);
+/* g_x[N,32,s,s] (may be NULL) = data gradient of g_out * (out > 0) (g_out, out in the shuffled [N,32,2s,2s] layout);
+ * w_partials [rows, 128*32*9], b_partials [rows, 128], rows = kvae_dec_up_partial_rows(N, side): column sums. */
+int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const float *g_out, float *g_x, float *w_partials,
+                    float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream);
+int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

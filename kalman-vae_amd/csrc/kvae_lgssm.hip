@@ -711,3 +711,39 @@ int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const fl
   return launch_status("k_enc_mid_wrw");
 }
 }  // extern "C"
+
+#include "vae_conv_up.h"
+static inline int64_t dec_up_grid(int64_t N, int32_t side) {
+  const int64_t fpi = side == 8 ? 2 : 8, iters = (N + fpi - 1) / fpi;
+  return iters < 256 ? (iters < 1 ? 1 : iters) : 256;   // one persistent workgroup per CU
+}
+extern "C" {
+int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side) { return dec_up_grid(N, side); }
+
+int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cin, int32_t side,
+                    void *stream) {
+  if (!x || !W || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1 || (N + 256 * 8) * UP_CO * side * side * 4 >= EM_MAX_BYTES) return KVAE_ERR_ARG;   // 32-bit byte offsets
+  if (Cin != UP_CI || (side != 8 && side != 4)) return KVAE_ERR_DIMS;
+  const dim3 grid((unsigned)dec_up_grid(N, side));
+  if (side == 8) k_dec_up_fwd<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+  else k_dec_up_fwd<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+  return launch_status("k_dec_up_fwd");
+}
+int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const float *g_out, float *g_x, float *w_partials,
+                    float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream) {
+  if (!x || !W || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1 || (N + 256 * 8) * UP_CO * side * side * 4 >= EM_MAX_BYTES) return KVAE_ERR_ARG;
+  if (Cin != UP_CI || (side != 8 && side != 4)) return KVAE_ERR_DIMS;
+  const dim3 grid((unsigned)dec_up_grid(N, side));
+  if (g_x) {
+    if (side == 8) k_dec_up_bwd_data<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
+    else k_dec_up_bwd_data<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
+    const int rc = launch_status("k_dec_up_bwd_data");
+    if (rc) return rc;
+  }
+  if (side == 8) k_dec_up_wrw<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+  else k_dec_up_wrw<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+  return launch_status("k_dec_up_wrw");
+}
+}  // extern "C"

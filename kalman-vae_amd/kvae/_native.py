@@ -50,6 +50,7 @@ SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_filter_fwd", "kvae_lgssm_
            "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
+           "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows",
            "kvae_abi_version",
            "kvae_last_error", "kvae_build_info")
 
@@ -113,6 +114,12 @@ class LgssmLib:
         d.kvae_enc_mid_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_mid_bwd.restype = C.c_int
         d.kvae_enc_mid_partial_rows.argtypes = [C.c_int64, C.c_int32]
+        d.kvae_dec_up_fwd.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_dec_up_fwd.restype = C.c_int
+        d.kvae_dec_up_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_dec_up_bwd.restype = C.c_int
+        d.kvae_dec_up_partial_rows.argtypes = [C.c_int64, C.c_int32]
+        d.kvae_dec_up_partial_rows.restype = C.c_int64
         d.kvae_enc_mid_partial_rows.restype = C.c_int64
         d.kvae_conv_edge_partial_rows.argtypes = [C.c_int64]
         d.kvae_conv_edge_partial_rows.restype = C.c_int64

@@ -134,7 +134,7 @@ class EncoderMid(torch.autograd.Function):
     def supported(x, conv):
         return (x.dim() == 4 and x.shape[1] == 32 and x.shape[2] == x.shape[3] and x.shape[2] in (16, 8)
                 and tuple(conv.weight.shape) == (32, 32, 3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
-                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and x.shape[0] <= 30000)
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -159,6 +159,46 @@ class EncoderMid(torch.autograd.Function):
         bp = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
                                            N.ptr(wp), N.ptr(bp), Nb, Cc, s, N.stream_for(x)), "kvae_enc_mid_bwd")
+        return g_x, colsum(wp).view_as(weight), colsum(bp)
+
+
+class DecoderUp(torch.autograd.Function):
+    """out[N,32,2s,2s] = relu(pixel_shuffle_2(conv3x3(x[N,32,s,s], W[128,32,3,3]) + b)), s in {8, 4}: implicit GEMMs on the
+    exact-f32 matrix cores with the weights stationary in registers (csrc/vae_conv_up.h; reference kvae/vae/vae.py:92-101).
+    Bias, PixelShuffle and ReLU are part of the kernels in both directions."""
+
+    MAX_FRAMES = 60000   # one launch addresses its tensors with 32-bit byte offsets
+
+    @staticmethod
+    def supported(x, conv):
+        return (x.dim() == 4 and x.shape[1] == 32 and x.shape[2] == x.shape[3] and x.shape[2] in (8, 4)
+                and tuple(conv.weight.shape) == (128, 32, 3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
+                and x.shape[0] <= DecoderUp.MAX_FRAMES)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        Nb, Cin, s, _ = x.shape
+        out = torch.empty(Nb, 32, 2 * s, 2 * s, device=x.device, dtype=torch.float32)
+        lib = N.lib_for(x)
+        lib.check(lib.dll.kvae_dec_up_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cin, s, N.stream_for(x)),
+                  "kvae_dec_up_fwd")
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        g = g.contiguous()
+        Nb, Cin, s, _ = x.shape
+        lib = N.lib_for(x)
+        rows = lib.dll.kvae_dec_up_partial_rows(Nb, s)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
+        bp = torch.empty(rows, 128, device=x.device, dtype=torch.float32)
+        lib.check(lib.dll.kvae_dec_up_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
+                                          N.ptr(wp), N.ptr(bp), Nb, Cin, s, N.stream_for(x)), "kvae_dec_up_bwd")
         return g_x, colsum(wp).view_as(weight), colsum(bp)
 
 

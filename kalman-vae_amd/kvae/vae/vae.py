@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from kvae import _native
 from kvae.utils.config import KVAEConfig
-from kvae.vae.fused import DecoderHead, EncoderMid, EncoderStem, conv_block
+from kvae.vae.fused import DecoderHead, DecoderUp, EncoderMid, EncoderStem, conv_block
 
 
 def _conv_out(size, k, s, p):
@@ -78,6 +78,8 @@ class Decoder(nn.Module):
                 relu = i + 2 < len(layers) and isinstance(layers[i + 2], nn.ReLU)
                 if not relu and DecoderHead.supported(h, layer):     # 4 output channels: direct kernel
                     h = DecoderHead.apply(h, layer.weight, layer.bias)
+                elif relu and DecoderUp.supported(h, layer):         # 32 -> 128 + shuffle + ReLU on the f32 matrix cores
+                    h = DecoderUp.apply(h, layer.weight, layer.bias)
                 else:
                     h = conv_block(h, layer, r=2, relu=relu)
         return h

@@ -483,3 +483,70 @@ int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const fl
   return KVAE_OK;
 }
 }
+
+// Decoder up-sampling blocks (conv 32 -> 128, 3x3 pad 1, PixelShuffle(2), ReLU): plain loops, same argument checks.
+extern "C" {
+static int64_t dec_up_grid_sim(int64_t N, int32_t side) {
+  const int64_t fpi = side == 8 ? 2 : 8, iters = (N + fpi - 1) / fpi;
+  return iters < 256 ? (iters < 1 ? 1 : iters) : 256;
+}
+int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side) { return dec_up_grid_sim(N, side); }
+
+int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cin, int32_t side,
+                    void *) {
+  if (!x || !W || !bias || !out) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cin != 32 || (side != 8 && side != 4)) return KVAE_ERR_DIMS;
+  const int S = side, O = 2 * side;
+  for (int64_t n = 0; n < N; ++n)
+    for (int co = 0; co < 128; ++co)
+      for (int h = 0; h < S; ++h)
+        for (int w = 0; w < S; ++w) {
+          float acc = bias[co];
+          for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int y = h + ky - 1, xx = w + kx - 1;
+                if (y < 0 || y >= S || xx < 0 || xx >= S) continue;
+                acc += W[((co * Cin + ci) * 3 + ky) * 3 + kx] * x[((n * Cin + ci) * S + y) * S + xx];
+              }
+          const int c = co / 4, dy = (co % 4) / 2, dx = co % 2;
+          out[((n * 32 + c) * O + 2 * h + dy) * O + 2 * w + dx] = acc > 0.f ? acc : 0.f;
+        }
+  return KVAE_OK;
+}
+int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const float *g_out, float *g_x, float *w_partials,
+                    float *b_partials, int64_t N, int32_t Cin, int32_t side, void *) {
+  if (!x || !W || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (Cin != 32 || (side != 8 && side != 4)) return KVAE_ERR_DIMS;
+  const int S = side, O = 2 * side;
+  const int64_t rows = kvae_dec_up_partial_rows(N, side);
+  memset(w_partials, 0, sizeof(float) * rows * 128 * Cin * 9);
+  memset(b_partials, 0, sizeof(float) * rows * 128);
+  if (g_x) memset(g_x, 0, sizeof(float) * N * Cin * S * S);
+  for (int64_t n = 0; n < N; ++n) {
+    float *wp = w_partials + (n % rows) * 128 * Cin * 9, *bp = b_partials + (n % rows) * 128;
+    for (int co = 0; co < 128; ++co)
+      for (int h = 0; h < S; ++h)
+        for (int w = 0; w < S; ++w) {
+          const int c = co / 4, dy = (co % 4) / 2, dx = co % 2;
+          const int64_t oi = ((n * 32 + c) * O + 2 * h + dy) * O + 2 * w + dx;
+          if (!(out[oi] > 0.f)) continue;
+          const float g = g_out[oi];
+          bp[co] += g;
+          for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int y = h + ky - 1, xx = w + kx - 1;
+                if (y < 0 || y >= S || xx < 0 || xx >= S) continue;
+                const int64_t ii = ((n * Cin + ci) * S + y) * S + xx;
+                const int wi = ((co * Cin + ci) * 3 + ky) * 3 + kx;
+                wp[wi] += g * x[ii];
+                if (g_x) g_x[ii] += g * W[wi];
+              }
+        }
+  }
+  return KVAE_OK;
+}
+}

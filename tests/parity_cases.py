@@ -246,3 +246,24 @@ def enc_mid_vs_torch(DEV, N, side):
     assert rel_err(out.detach().cpu(), ref.detach()) < 3e-5
     for a, r in ((xd, xr), (Wd, Wr), (bd, br)):
         assert rel_err(a.grad.cpu(), r.grad) < 3e-5
+
+
+def dec_up_vs_torch(DEV, N, side):
+    """Register-stationary MFMA decoder blocks == relu(pixel_shuffle(conv2d)) of torch, values and all three gradients.
+    Tolerance 3e-5 relative (fp32; different summation order over 288 / 1152 taps and over the frames)."""
+    import torch.nn.functional as F
+    from kvae.vae.fused import DecoderUp
+    g = torch.Generator().manual_seed(N * side + 1)
+    x = torch.relu(torch.randn(N, 32, side, side, generator=g))
+    W = 0.08 * torch.randn(128, 32, 3, 3, generator=g)
+    b = 0.1 * torch.randn(128, generator=g)
+    up = torch.randn(N, 32, 2 * side, 2 * side, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    ref = torch.relu(F.pixel_shuffle(F.conv2d(xr, Wr, br, padding=1), 2))
+    (ref * up).sum().backward()
+    xd, Wd, bd = (t.clone().to(DEV).requires_grad_(True) for t in (x, W, b))
+    out = DecoderUp.apply(xd, Wd, bd)
+    (out * up.to(DEV)).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < 3e-5
+    for a, r in ((xd, xr), (Wd, Wr), (bd, br)):
+        assert rel_err(a.grad.cpu(), r.grad) < 3e-5

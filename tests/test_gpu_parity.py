@@ -193,6 +193,12 @@ def test_conv_edge_gpu(N):
     parity_cases.conv_edge_vs_torch(DEV, N)
 
 
+@pytest.mark.parametrize("N,side", [(1, 8), (2, 8), (7, 8), (1031, 8), (1, 4), (8, 4), (13, 4), (4099, 4)])
+def test_dec_up_gpu(N, side):
+    """Register-stationary MFMA decoder blocks vs torch (ragged last iteration, more iterations than workgroups)."""
+    parity_cases.dec_up_vs_torch(DEV, N, side)
+
+
 @pytest.mark.parametrize("N,side", [(1, 16), (2, 16), (7, 16), (1031, 16), (1, 8), (8, 8), (13, 8), (4099, 8)])
 def test_enc_mid_gpu(N, side):
     """MFMA stride-2 encoder layers vs torch; odd frame counts exercise the ragged last iteration, the large ones the

@@ -63,3 +63,18 @@ for side in (16, 8):
     rm = torch.relu(F.conv2d(xm, Wm, bm, stride=2, padding=1))
     print(f"  miopen fwd+relu       {timed(lambda: torch.relu(F.conv2d(xm, Wm, bm, stride=2, padding=1))):8.1f} us")
     print(f"  miopen bwd            {timed(lambda: torch.autograd.grad(rm, (xm, Wm, bm), upm, retain_graph=True)):8.1f} us")
+
+from kvae.vae.fused import DecoderUp
+for side in (8, 4):
+    xm = torch.relu(torch.randn(N, 32, side, side, device=dev)).requires_grad_(True)
+    Wm = (0.08 * torch.randn(128, 32, 3, 3, device=dev)).requires_grad_(True)
+    bm = torch.randn(128, device=dev, requires_grad=True)
+    upm = torch.randn(N, 32, 2 * side, 2 * side, device=dev)
+    om = DecoderUp.apply(xm, Wm, bm)
+    gmac = N * side ** 2 * 128 * 288 / 1e9
+    print(f"dec_up s={side} ({gmac:.1f} GMAC/pass, MFMA-f32 floor {2 * gmac / 157e3 * 1e6:.0f} us)")
+    print(f"  mfma   fwd            {timed(lambda: DecoderUp.apply(xm, Wm, bm)):8.1f} us")
+    print(f"  mfma   bwd (data+w)   {timed(lambda: torch.autograd.grad(om, (xm, Wm, bm), upm, retain_graph=True)):8.1f} us")
+    rm = torch.relu(F.pixel_shuffle(F.conv2d(xm, Wm, bm, padding=1), 2))
+    print(f"  miopen fwd+shuffle+relu {timed(lambda: torch.relu(F.pixel_shuffle(F.conv2d(xm, Wm, bm, padding=1), 2))):8.1f} us")
+    print(f"  miopen bwd            {timed(lambda: torch.autograd.grad(rm, (xm, Wm, bm), upm, retain_graph=True)):8.1f} us")
