@@ -345,8 +345,42 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
 // ---------------------------------------------------------------------------------------------
 #include "vae_epilogue.h"
 
-// out[c] = sum_r partials[r, c]: second stage of every deterministic two-stage reduction of the VAE kernels (bias and
-// weight gradient partial rows).  64 columns x 4 row lanes per block: coalesced along c, rows folded through LDS.
+// out[c] = sum_r partials[r, c]: second stage of every deterministic two-stage reduction (bias / weight gradient partial
+// rows).  HBM-bound (the 32->128 layers hand over 256 x 36864 floats = 38 MB): a lane owns four columns (dwordx4, 1 KiB per
+// wave and row), the eight waves of a block take every eighth row, four rows in flight per wave, fold through LDS.
+__global__ __launch_bounds__(512) void k_colsum_v4(const float *__restrict__ partials, float *__restrict__ out, int64_t rows,
+                                                   int64_t cols) {
+  __shared__ float4 red[8][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (c < cols) {
+    const float *p = partials + c;
+    int64_t r = wv;
+    for (; r + 24 < rows; r += 32) {
+      const float4 a = *reinterpret_cast<const float4 *>(p + r * cols), b = *reinterpret_cast<const float4 *>(p + (r + 8) * cols),
+                   d = *reinterpret_cast<const float4 *>(p + (r + 16) * cols), e = *reinterpret_cast<const float4 *>(p + (r + 24) * cols);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += d.x; s2.y += d.y; s2.z += d.z; s2.w += d.w;
+      s3.x += e.x; s3.y += e.y; s3.z += e.z; s3.w += e.w;
+    }
+    for (; r < rows; r += 8) {
+      const float4 a = *reinterpret_cast<const float4 *>(p + r * cols);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+  }
+  red[wv][lane] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                              (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  if (wv == 0 && c < cols) {
+    float4 t = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) { const float4 u = red[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4 *>(out + c) = t;
+  }
+}
+// any column count (scalar): 64 columns x 4 row lanes per block
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partials, float *__restrict__ out, int64_t rows,
                                                 int64_t cols) {
   __shared__ float red[256];
@@ -494,7 +528,10 @@ int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in,
 int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, void *stream) {
   if (!partials || !out) return KVAE_ERR_NULL;
   if (rows < 1 || cols < 1) return KVAE_ERR_ARG;
-  k_colsum<<<dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(partials, out, rows, cols);
+  if ((cols & 3) == 0 && ((((uintptr_t)partials | (uintptr_t)out) & 15) == 0))
+    k_colsum_v4<<<dim3((unsigned)((cols + 255) / 256)), dim3(512), 0, (hipStream_t)stream>>>(partials, out, rows, cols);
+  else
+    k_colsum<<<dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(partials, out, rows, cols);
   return launch_status("k_colsum");
 }
 int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHUNK - 1) / KVAE_EPI_SAMPLES_PER_CHUNK; }
