@@ -260,6 +260,30 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
                     float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream);
 int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side);
 
+/* ---- skinny fully-connected ends of the frame VAE and the latent regulariser --------------- */
+
+/* Encoder heads (kvae/vae/vae.py:33-41) + reparameterisation (kvae/model/model.py:81-84), F = 512, A = 2:
+ * mu = feat Wmu^T + bmu; var = noise_emission * sigmoid(feat Wvar^T + bvar); a = mu + eps * sqrt(var + 1e-6)
+ * (eps may be NULL: a = mu).  Other shapes return KVAE_ERR_DIMS. */
+int kvae_enc_head_fwd(const float *feat, const float *Wmu, const float *bmu, const float *Wvar, const float *bvar,
+                      const float *eps, float *mu, float *var, float *a, int64_t N, int32_t F, int32_t A,
+                      float noise_emission, void *stream);
+/* Upstream g_a, g_mu, g_var ([N,A]; each may be NULL = 0) -> g_feat [N,F]; w_partials [rows, 2*A*F] laid out
+ * (Wmu | Wvar) and b_partials [rows, 2*A] (bmu | bvar), rows = kvae_head_partial_rows(): column sums. */
+int kvae_enc_head_bwd(const float *feat, const float *Wmu, const float *Wvar, const float *var, const float *eps,
+                      const float *g_a, const float *g_mu, const float *g_var, float *g_feat, float *w_partials,
+                      float *b_partials, int64_t N, int32_t F, int32_t A, float noise_emission, void *stream);
+/* Decoder fc (kvae/vae/vae.py:88-90): h[N,F] = a[N,A] W[F,A]^T + b[F], and its gradients (partial rows as above:
+ * w_partials [rows, F*A], b_partials [rows, F]). */
+int kvae_dec_fc_fwd(const float *a, const float *W, const float *b, float *h, int64_t N, int32_t F, int32_t A, void *stream);
+int kvae_dec_fc_bwd(const float *g_h, const float *a, const float *W, float *g_a, float *w_partials, float *b_partials,
+                    int64_t N, int32_t F, int32_t A, void *stream);
+int64_t kvae_head_partial_rows(void);
+/* reg[n] = sum_j log N(a_nj; 0, 1) - log N(a_nj; mu_nj, var_nj) (kvae/vae/losses.py:64-66) and its three gradients. */
+int kvae_latent_reg_fwd(const float *a, const float *mu, const float *var, float *reg, int64_t N, int32_t A, void *stream);
+int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const float *g, float *g_a, float *g_mu,
+                        float *g_var, int64_t N, int32_t A, void *stream);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

@@ -784,3 +784,57 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
   return launch_status("k_dec_up_wrw");
 }
 }  // extern "C"
+
+#include "vae_heads.h"
+extern "C" {
+int64_t kvae_head_partial_rows(void) { return HD_WAVES; }
+
+int kvae_enc_head_fwd(const float *feat, const float *Wmu, const float *bmu, const float *Wvar, const float *bvar,
+                      const float *eps, float *mu, float *var, float *a, int64_t N, int32_t F, int32_t A,
+                      float noise_emission, void *stream) {
+  if (!feat || !Wmu || !bmu || !Wvar || !bvar || !mu || !var || !a) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != HD_F || A != HD_A) return KVAE_ERR_DIMS;
+  const unsigned grid = (unsigned)(N < 4 * 512 ? (N + 3) / 4 : 512);
+  k_enc_head_fwd<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(feat, Wmu, bmu, Wvar, bvar, eps, noise_emission, mu, var, a, N);
+  return launch_status("k_enc_head_fwd");
+}
+int kvae_enc_head_bwd(const float *feat, const float *Wmu, const float *Wvar, const float *var, const float *eps,
+                      const float *g_a, const float *g_mu, const float *g_var, float *g_feat, float *w_partials,
+                      float *b_partials, int64_t N, int32_t F, int32_t A, float noise_emission, void *stream) {
+  if (!feat || !Wmu || !Wvar || !var || !g_feat || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != HD_F || A != HD_A) return KVAE_ERR_DIMS;
+  k_enc_head_bwd<<<dim3(HD_WAVES / 4), dim3(256), 0, (hipStream_t)stream>>>(feat, Wmu, Wvar, var, eps, g_a, g_mu, g_var,
+                                                                             noise_emission, g_feat, w_partials, b_partials, N);
+  return launch_status("k_enc_head_bwd");
+}
+int kvae_dec_fc_fwd(const float *a, const float *W, const float *b, float *h, int64_t N, int32_t F, int32_t A, void *stream) {
+  if (!a || !W || !b || !h) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != HD_F || A != HD_A) return KVAE_ERR_DIMS;
+  k_dec_fc_fwd<<<dim3(epi_grid(N * (HD_F / 4))), dim3(256), 0, (hipStream_t)stream>>>(a, W, b, h, N * (HD_F / 4));
+  return launch_status("k_dec_fc_fwd");
+}
+int kvae_dec_fc_bwd(const float *g_h, const float *a, const float *W, float *g_a, float *w_partials, float *b_partials,
+                    int64_t N, int32_t F, int32_t A, void *stream) {
+  if (!g_h || !a || !W || !g_a || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != HD_F || A != HD_A) return KVAE_ERR_DIMS;
+  k_dec_fc_bwd<<<dim3(HD_WAVES / 4), dim3(256), 0, (hipStream_t)stream>>>(g_h, a, W, g_a, w_partials, b_partials, N);
+  return launch_status("k_dec_fc_bwd");
+}
+int kvae_latent_reg_fwd(const float *a, const float *mu, const float *var, float *reg, int64_t N, int32_t A, void *stream) {
+  if (!a || !mu || !var || !reg) return KVAE_ERR_NULL;
+  if (N < 1 || A < 1) return KVAE_ERR_ARG;
+  k_latent_reg_fwd<<<dim3(epi_grid(N)), dim3(256), 0, (hipStream_t)stream>>>(a, mu, var, reg, N, A);
+  return launch_status("k_latent_reg_fwd");
+}
+int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const float *g, float *g_a, float *g_mu,
+                        float *g_var, int64_t N, int32_t A, void *stream) {
+  if (!a || !mu || !var || !g || !g_a || !g_mu || !g_var) return KVAE_ERR_NULL;
+  if (N < 1 || A < 1) return KVAE_ERR_ARG;
+  k_latent_reg_bwd<<<dim3(epi_grid(N * A)), dim3(256), 0, (hipStream_t)stream>>>(a, mu, var, g, g_a, g_mu, g_var, N, A);
+  return launch_status("k_latent_reg_bwd");
+}
+}  // extern "C"

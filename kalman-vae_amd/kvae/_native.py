@@ -51,6 +51,8 @@ SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_filter_fwd", "kvae_lgssm_
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
            "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows",
+           "kvae_enc_head_fwd", "kvae_enc_head_bwd", "kvae_dec_fc_fwd", "kvae_dec_fc_bwd", "kvae_head_partial_rows",
+           "kvae_latent_reg_fwd", "kvae_latent_reg_bwd",
            "kvae_abi_version",
            "kvae_last_error", "kvae_build_info")
 
@@ -119,6 +121,20 @@ class LgssmLib:
         d.kvae_dec_up_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_dec_up_bwd.restype = C.c_int
         d.kvae_dec_up_partial_rows.argtypes = [C.c_int64, C.c_int32]
+        d.kvae_enc_head_fwd.argtypes = [vp] * 9 + [C.c_int64, C.c_int32, C.c_int32, C.c_float, vp]
+        d.kvae_enc_head_fwd.restype = C.c_int
+        d.kvae_enc_head_bwd.argtypes = [vp] * 11 + [C.c_int64, C.c_int32, C.c_int32, C.c_float, vp]
+        d.kvae_enc_head_bwd.restype = C.c_int
+        d.kvae_dec_fc_fwd.argtypes = [vp] * 4 + [C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_dec_fc_fwd.restype = C.c_int
+        d.kvae_dec_fc_bwd.argtypes = [vp] * 6 + [C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_dec_fc_bwd.restype = C.c_int
+        d.kvae_head_partial_rows.argtypes = []
+        d.kvae_head_partial_rows.restype = C.c_int64
+        d.kvae_latent_reg_fwd.argtypes = [vp] * 4 + [C.c_int64, C.c_int32, vp]
+        d.kvae_latent_reg_fwd.restype = C.c_int
+        d.kvae_latent_reg_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, vp]
+        d.kvae_latent_reg_bwd.restype = C.c_int
         d.kvae_dec_up_partial_rows.restype = C.c_int64
         d.kvae_enc_mid_partial_rows.restype = C.c_int64
         d.kvae_conv_edge_partial_rows.argtypes = [C.c_int64]

@@ -62,8 +62,13 @@ class KVAE(nn.Module):
 
     def encode_sequence(self, x):
         lead = x.shape[:2]
-        mu, var = self.encoder(x.flatten(0, 1))
-        a = self.reparameterize(mu, var)
+        feat = self.encoder.features(x.flatten(0, 1))
+        eps = noise.take("eps_a")
+        if eps is None:
+            eps = torch.randn(feat.shape[0], self.config.a_dim, device=feat.device, dtype=feat.dtype)
+        else:
+            eps = eps.to(device=feat.device, dtype=feat.dtype).reshape(feat.shape[0], self.config.a_dim)
+        a, mu, var = self.encoder.heads(feat, eps)   # both heads + reparameterisation: one kernel on the GPU path
         return a.unflatten(0, lead), mu.unflatten(0, lead), var.unflatten(0, lead)
 
     def decode_sequence(self, a):

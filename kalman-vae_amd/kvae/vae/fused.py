@@ -202,6 +202,111 @@ class DecoderUp(torch.autograd.Function):
         return g_x, colsum(wp).view_as(weight), colsum(bp)
 
 
+def _optr(t):
+    return N.ptr(t) if t is not None else None
+
+
+class EncoderHead(torch.autograd.Function):
+    """(a, mu, var) from the flattened encoder features in one kernel: fc_mu, fc_var + Sigmoid, noise_emission and the
+    reparameterisation a = mu + eps sqrt(var + 1e-6) (reference kvae/vae/vae.py:33-41, kvae/model/model.py:81-84);
+    eps=None gives a = mu.  csrc/vae_heads.h."""
+
+    @staticmethod
+    def supported(feat, fc_mu, fc_var_lin):
+        return (feat.dim() == 2 and feat.shape[1] == 512 and tuple(fc_mu.weight.shape) == (2, 512)
+                and tuple(fc_var_lin.weight.shape) == (2, 512) and fc_mu.bias is not None and fc_var_lin.bias is not None)
+
+    @staticmethod
+    def forward(ctx, feat, w_mu, b_mu, w_var, b_var, eps, ne):
+        feat, w_mu, b_mu, w_var, b_var = (t.contiguous() for t in (feat, w_mu, b_mu, w_var, b_var))
+        eps = eps.contiguous() if eps is not None else None
+        Nb = feat.shape[0]
+        mu, var, a = (torch.empty(Nb, 2, device=feat.device, dtype=torch.float32) for _ in range(3))
+        lib = N.lib_for(feat)
+        lib.check(lib.dll.kvae_enc_head_fwd(N.ptr(feat), N.ptr(w_mu), N.ptr(b_mu), N.ptr(w_var), N.ptr(b_var), _optr(eps),
+                                            N.ptr(mu), N.ptr(var), N.ptr(a), Nb, 512, 2, float(ne), N.stream_for(feat)),
+                  "kvae_enc_head_fwd")
+        ctx.save_for_backward(feat, w_mu, w_var, var, eps)
+        ctx.ne = float(ne)
+        return a, mu, var
+
+    @staticmethod
+    def backward(ctx, g_a, g_mu, g_var):
+        feat, w_mu, w_var, var, eps = ctx.saved_tensors
+        g_a, g_mu, g_var = (t.contiguous() if t is not None else None for t in (g_a, g_mu, g_var))
+        Nb = feat.shape[0]
+        lib = N.lib_for(feat)
+        rows = lib.dll.kvae_head_partial_rows()
+        g_feat = torch.empty_like(feat)
+        wp = torch.empty(rows, 4 * 512, device=feat.device, dtype=torch.float32)
+        bp = torch.empty(rows, 4, device=feat.device, dtype=torch.float32)
+        lib.check(lib.dll.kvae_enc_head_bwd(N.ptr(feat), N.ptr(w_mu), N.ptr(w_var), N.ptr(var), _optr(eps), _optr(g_a), _optr(g_mu),
+                                            _optr(g_var), N.ptr(g_feat), N.ptr(wp), N.ptr(bp), Nb, 512, 2, ctx.ne,
+                                            N.stream_for(feat)), "kvae_enc_head_bwd")
+        gw, gb = colsum(wp).view(2, 2, 512), colsum(bp).view(2, 2)
+        return g_feat, gw[0], gb[0], gw[1], gb[1], None, None
+
+
+class DecoderFc(torch.autograd.Function):
+    """h[N,512] = a[N,2] W[512,2]^T + b (reference kvae/vae/vae.py:88-90) and its gradients, one kernel each way."""
+
+    @staticmethod
+    def supported(a, fc):
+        return a.dim() == 2 and a.shape[1] == 2 and tuple(fc.weight.shape) == (512, 2) and fc.bias is not None
+
+    @staticmethod
+    def forward(ctx, a, weight, bias):
+        a, weight, bias = a.contiguous(), weight.contiguous(), bias.contiguous()
+        Nb = a.shape[0]
+        h = torch.empty(Nb, 512, device=a.device, dtype=torch.float32)
+        lib = N.lib_for(a)
+        lib.check(lib.dll.kvae_dec_fc_fwd(N.ptr(a), N.ptr(weight), N.ptr(bias), N.ptr(h), Nb, 512, 2, N.stream_for(a)),
+                  "kvae_dec_fc_fwd")
+        ctx.save_for_backward(a, weight)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        a, weight = ctx.saved_tensors
+        g = g.contiguous()
+        Nb = a.shape[0]
+        lib = N.lib_for(a)
+        rows = lib.dll.kvae_head_partial_rows()
+        g_a = torch.empty_like(a)
+        wp = torch.empty(rows, 1024, device=a.device, dtype=torch.float32)
+        bp = torch.empty(rows, 512, device=a.device, dtype=torch.float32)
+        lib.check(lib.dll.kvae_dec_fc_bwd(N.ptr(g), N.ptr(a), N.ptr(weight), N.ptr(g_a), N.ptr(wp), N.ptr(bp), Nb, 512, 2,
+                                          N.stream_for(a)), "kvae_dec_fc_bwd")
+        return g_a, colsum(wp).view(512, 2), colsum(bp)
+
+
+class LatentReg(torch.autograd.Function):
+    """[...]-shaped sum over the latent dimension of log N(a;0,1) - log N(a;mu,var) (reference kvae/vae/losses.py:64-66)."""
+
+    @staticmethod
+    def forward(ctx, a, mu, var):
+        a, mu, var = a.contiguous(), mu.contiguous(), var.contiguous()
+        A = a.shape[-1]
+        Nb = a.numel() // A
+        reg = torch.empty(a.shape[:-1], device=a.device, dtype=torch.float32)
+        lib = N.lib_for(a)
+        lib.check(lib.dll.kvae_latent_reg_fwd(N.ptr(a), N.ptr(mu), N.ptr(var), N.ptr(reg), Nb, A, N.stream_for(a)),
+                  "kvae_latent_reg_fwd")
+        ctx.save_for_backward(a, mu, var)
+        return reg
+
+    @staticmethod
+    def backward(ctx, g):
+        a, mu, var = ctx.saved_tensors
+        g = g.contiguous()
+        A = a.shape[-1]
+        g_a, g_mu, g_var = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        lib = N.lib_for(a)
+        lib.check(lib.dll.kvae_latent_reg_bwd(N.ptr(a), N.ptr(mu), N.ptr(var), N.ptr(g), N.ptr(g_a), N.ptr(g_mu), N.ptr(g_var),
+                                              a.numel() // A, A, N.stream_for(a)), "kvae_latent_reg_bwd")
+        return g_a, g_mu, g_var
+
+
 class BernoulliFrameLogLik(torch.autograd.Function):
     """[B,T] log p(x_t | a_t) = -sum_pixels BCEWithLogits(x_logits, x) (reference kvae/vae/losses.py:85-87) in one pass."""
 

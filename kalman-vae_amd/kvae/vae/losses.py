@@ -36,8 +36,19 @@ def vae_loss(x, x_mu, x_var, a, a_mu, a_var, scale_reconstruction: float = 0.3, 
     vae_elbo = scale_reconstruction * E[log p(x|a)] + beta * (log p(a) - log q(a|x))."""
     mk = _frame_mask(mask, x)
     denom = mk.sum().clamp(min=1.0)
+    from kvae import _native
+    if out_distr.lower() == "bernoulli" and _native.fused_ok(a) and a.dtype == torch.float32 and a_var.dim() == a.dim():
+        # GPU training path: Bernoulli frame term and the latent regulariser as one fused op each (csrc/vae_loss.h,
+        # csrc/vae_heads.h); same quantities as the generic code below
+        from kvae.vae.fused import BernoulliFrameLogLik, LatentReg
+        if x_mu.dtype == torch.float32 and x.dtype == torch.float32 and not x.requires_grad:
+            lpx = BernoulliFrameLogLik.apply(x_mu, x)
+        else:
+            lpx = -F.binary_cross_entropy_with_logits(x_mu, x, reduction="none").sum(dim=(2, 3, 4))
+        recon = (lpx * mk).sum() / denom
+        reg = (LatentReg.apply(a, a_mu, a_var) * mk).sum() / denom
+        return scale_reconstruction * recon + beta * reg, recon, reg
     if out_distr.lower() == "bernoulli":
-        from kvae import _native
         if _native.fused_ok(x_mu) and x_mu.dtype == torch.float32 and x.dtype == torch.float32 and not x.requires_grad:
             from kvae.vae.fused import BernoulliFrameLogLik
             lpx = BernoulliFrameLogLik.apply(x_mu, x)    # one HIP pass per direction (csrc/vae_loss.h)

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from kvae import _native
 from kvae.utils.config import KVAEConfig
-from kvae.vae.fused import DecoderHead, DecoderUp, EncoderMid, EncoderStem, conv_block
+from kvae.vae.fused import DecoderFc, DecoderHead, DecoderUp, EncoderHead, EncoderMid, EncoderStem, conv_block
 
 
 def _conv_out(size, k, s, p):
@@ -35,9 +35,10 @@ class Encoder(nn.Module):
         self.fc_mu = nn.Linear(self.flat_size, config.a_dim)
         self.fc_var = nn.Sequential(nn.Linear(self.flat_size, config.a_dim), nn.Sigmoid())
 
-    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        """Flattened output of the convolution stack, [N, flat_size]."""
         if _native.fused_ok(x) and x.dtype == torch.float32:
-            h = x   # conv on MIOpen, then ONE fused bias+ReLU pass per layer (csrc/vae_epilogue.h)
+            h = x   # hand-written convolutions for the reference's shapes; otherwise MIOpen + one fused epilogue pass
             for i, layer in enumerate(self.conv_layers):
                 if isinstance(layer, nn.Conv2d):
                     if i == 0 and EncoderStem.supported(h, layer):   # 1 input channel: direct kernel, not a GEMM
@@ -46,10 +47,21 @@ class Encoder(nn.Module):
                         h = EncoderMid.apply(h, layer.weight, layer.bias)
                     else:
                         h = conv_block(h, layer, r=1, relu=True)
-            feat = h.flatten(1)
-        else:
-            feat = self.conv_layers(x).flatten(1)
-        return self.fc_mu(feat), self.config.noise_emission * self.fc_var(feat)
+            return h.flatten(1)
+        return self.conv_layers(x).flatten(1)
+
+    def heads(self, feat: torch.Tensor, eps=None):
+        """(a, mu, var): both heads and, if eps is given, the reparameterisation a = mu + eps sqrt(var + 1e-6) in one
+        kernel (csrc/vae_heads.h); a is mu when eps is None."""
+        if _native.fused_ok(feat) and feat.dtype == torch.float32 and EncoderHead.supported(feat, self.fc_mu, self.fc_var[0]):
+            return EncoderHead.apply(feat, self.fc_mu.weight, self.fc_mu.bias, self.fc_var[0].weight, self.fc_var[0].bias,
+                                     eps, self.config.noise_emission)
+        mu, var = self.fc_mu(feat), self.config.noise_emission * self.fc_var(feat)
+        return (mu if eps is None else mu + eps * torch.sqrt(var + 1e-6)), mu, var
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        _, mu, var = self.heads(self.features(x))
+        return mu, var
 
 
 class Decoder(nn.Module):
@@ -69,8 +81,10 @@ class Decoder(nn.Module):
         self.deconv_layers = nn.Sequential(*up)
 
     def forward(self, a: torch.Tensor) -> torch.Tensor:
-        h = self.fc(a).unflatten(1, (self.init_channels, self.init_size, self.init_size))
-        if not (_native.fused_ok(h) and h.dtype == torch.float32):
+        fused = _native.fused_ok(a) and a.dtype == torch.float32
+        h = DecoderFc.apply(a, self.fc.weight, self.fc.bias) if fused and DecoderFc.supported(a, self.fc) else self.fc(a)
+        h = h.unflatten(1, (self.init_channels, self.init_size, self.init_size))
+        if not fused:
             return self.deconv_layers(h)
         layers = list(self.deconv_layers)   # conv -> PixelShuffle(2) [-> ReLU] triples, fused per conv
         for i, layer in enumerate(layers):

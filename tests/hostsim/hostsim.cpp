@@ -550,3 +550,111 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
   return KVAE_OK;
 }
 }
+
+// Skinny fc ends of the VAE and the latent regulariser: plain loops, same argument checks as the HIP launchers.
+#include <math.h>
+extern "C" {
+int64_t kvae_head_partial_rows(void) { return 1024; }
+
+int kvae_enc_head_fwd(const float *feat, const float *Wmu, const float *bmu, const float *Wvar, const float *bvar,
+                      const float *eps, float *mu, float *var, float *a, int64_t N, int32_t F, int32_t A, float ne, void *) {
+  if (!feat || !Wmu || !bmu || !Wvar || !bvar || !mu || !var || !a) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != 512 || A != 2) return KVAE_ERR_DIMS;
+  for (int64_t n = 0; n < N; ++n)
+    for (int j = 0; j < A; ++j) {
+      float dm = bmu[j], dv = bvar[j];
+      for (int k = 0; k < F; ++k) { dm += feat[n * F + k] * Wmu[j * F + k]; dv += feat[n * F + k] * Wvar[j * F + k]; }
+      const float s = ne * (1.f / (1.f + expf(-dv)));
+      mu[n * A + j] = dm;
+      var[n * A + j] = s;
+      a[n * A + j] = eps ? dm + eps[n * A + j] * sqrtf(s + 1e-6f) : dm;
+    }
+  return KVAE_OK;
+}
+int kvae_enc_head_bwd(const float *feat, const float *Wmu, const float *Wvar, const float *var, const float *eps,
+                      const float *g_a, const float *g_mu, const float *g_var, float *g_feat, float *w_partials,
+                      float *b_partials, int64_t N, int32_t F, int32_t A, float ne, void *) {
+  if (!feat || !Wmu || !Wvar || !var || !g_feat || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != 512 || A != 2) return KVAE_ERR_DIMS;
+  const int64_t rows = kvae_head_partial_rows();
+  memset(w_partials, 0, sizeof(float) * rows * 2 * A * F);
+  memset(b_partials, 0, sizeof(float) * rows * 2 * A);
+  for (int64_t n = 0; n < N; ++n) {
+    float *wp = w_partials + (n % rows) * 2 * A * F, *bp = b_partials + (n % rows) * 2 * A;
+    for (int k = 0; k < F; ++k) g_feat[n * F + k] = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float ga = g_a ? g_a[n * A + j] : 0.f, s = var[n * A + j];
+      const float gm = (g_mu ? g_mu[n * A + j] : 0.f) + ga;
+      const float gv = (g_var ? g_var[n * A + j] : 0.f) + (eps ? ga * eps[n * A + j] * 0.5f / sqrtf(s + 1e-6f) : 0.f);
+      const float gs = gv * s * (1.f - s / ne);
+      for (int k = 0; k < F; ++k) {
+        g_feat[n * F + k] += gm * Wmu[j * F + k] + gs * Wvar[j * F + k];
+        wp[j * F + k] += gm * feat[n * F + k];
+        wp[(A + j) * F + k] += gs * feat[n * F + k];
+      }
+      bp[j] += gm;
+      bp[A + j] += gs;
+    }
+  }
+  return KVAE_OK;
+}
+int kvae_dec_fc_fwd(const float *a, const float *W, const float *b, float *h, int64_t N, int32_t F, int32_t A, void *) {
+  if (!a || !W || !b || !h) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != 512 || A != 2) return KVAE_ERR_DIMS;
+  for (int64_t n = 0; n < N; ++n)
+    for (int k = 0; k < F; ++k) h[n * F + k] = a[n * A] * W[k * A] + a[n * A + 1] * W[k * A + 1] + b[k];
+  return KVAE_OK;
+}
+int kvae_dec_fc_bwd(const float *g_h, const float *a, const float *W, float *g_a, float *w_partials, float *b_partials,
+                    int64_t N, int32_t F, int32_t A, void *) {
+  if (!g_h || !a || !W || !g_a || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (N < 1) return KVAE_ERR_ARG;
+  if (F != 512 || A != 2) return KVAE_ERR_DIMS;
+  const int64_t rows = kvae_head_partial_rows();
+  memset(w_partials, 0, sizeof(float) * rows * F * A);
+  memset(b_partials, 0, sizeof(float) * rows * F);
+  for (int64_t n = 0; n < N; ++n) {
+    float *wp = w_partials + (n % rows) * F * A, *bp = b_partials + (n % rows) * F;
+    float d0 = 0.f, d1 = 0.f;
+    for (int k = 0; k < F; ++k) {
+      const float g = g_h[n * F + k];
+      d0 += g * W[k * A];
+      d1 += g * W[k * A + 1];
+      wp[k * A] += g * a[n * A];
+      wp[k * A + 1] += g * a[n * A + 1];
+      bp[k] += g;
+    }
+    g_a[n * A] = d0;
+    g_a[n * A + 1] = d1;
+  }
+  return KVAE_OK;
+}
+int kvae_latent_reg_fwd(const float *a, const float *mu, const float *var, float *reg, int64_t N, int32_t A, void *) {
+  if (!a || !mu || !var || !reg) return KVAE_ERR_NULL;
+  if (N < 1 || A < 1) return KVAE_ERR_ARG;
+  for (int64_t n = 0; n < N; ++n) {
+    float s = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float x = a[n * A + j], d = x - mu[n * A + j], v = var[n * A + j];
+      s += (-0.5f * x * x) - (-0.5f * logf(v) - d * d / (2.f * v));
+    }
+    reg[n] = s;
+  }
+  return KVAE_OK;
+}
+int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const float *g, float *g_a, float *g_mu,
+                        float *g_var, int64_t N, int32_t A, void *) {
+  if (!a || !mu || !var || !g || !g_a || !g_mu || !g_var) return KVAE_ERR_NULL;
+  if (N < 1 || A < 1) return KVAE_ERR_ARG;
+  for (int64_t i = 0; i < N * A; ++i) {
+    const float x = a[i], d = x - mu[i], v = var[i], gg = g[i / A];
+    g_a[i] = gg * (-x + d / v);
+    g_mu[i] = gg * (-d / v);
+    g_var[i] = gg * (0.5f / v - d * d / (2.f * v * v));
+  }
+  return KVAE_OK;
+}
+}

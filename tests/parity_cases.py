@@ -1,4 +1,6 @@
 """Device-agnostic parity cases: run against the host simulation (CPU tier) and the gfx950 library (GPU tier)."""
+import math
+
 import torch
 
 from golden_util import rel_err
@@ -267,3 +269,56 @@ def dec_up_vs_torch(DEV, N, side):
     assert rel_err(out.detach().cpu(), ref.detach()) < 3e-5
     for a, r in ((xd, xr), (Wd, Wr), (bd, br)):
         assert rel_err(a.grad.cpu(), r.grad) < 3e-5
+
+
+def vae_heads_vs_torch(DEV, N):
+    """Fused encoder heads (+ reparameterisation), decoder fc and latent regulariser == the torch expressions of the
+    reference, values and gradients.  Tolerance 2e-5 relative (fp32, different summation order over 512 features / N rows)."""
+    import torch.nn.functional as F
+    from kvae.vae.fused import DecoderFc, EncoderHead, LatentReg
+    g = torch.Generator().manual_seed(N + 7)
+    feat = torch.relu(torch.randn(N, 512, generator=g))
+    Wm, bm = 0.05 * torch.randn(2, 512, generator=g), 0.1 * torch.randn(2, generator=g)
+    Wv, bv = 0.05 * torch.randn(2, 512, generator=g), 0.1 * torch.randn(2, generator=g)
+    eps = torch.randn(N, 2, generator=g)
+    ups = [torch.randn(N, 2, generator=g) for _ in range(3)]
+    ne = 0.03
+    ref_in = [t.clone().requires_grad_(True) for t in (feat, Wm, bm, Wv, bv)]
+    mu = F.linear(ref_in[0], ref_in[1], ref_in[2])
+    var = ne * torch.sigmoid(F.linear(ref_in[0], ref_in[3], ref_in[4]))
+    a = mu + eps * torch.sqrt(var + 1e-6)
+    (a * ups[0] + mu * ups[1] + var * ups[2]).sum().backward()
+    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (feat, Wm, bm, Wv, bv)]
+    a_d, mu_d, var_d = EncoderHead.apply(*dev_in, eps.to(DEV), ne)
+    (a_d * ups[0].to(DEV) + mu_d * ups[1].to(DEV) + var_d * ups[2].to(DEV)).sum().backward()
+    for got, want in ((a_d, a), (mu_d, mu), (var_d, var)):
+        assert rel_err(got.detach().cpu(), want.detach()) < 2e-5
+    for got, want in zip(dev_in, ref_in):
+        assert rel_err(got.grad.cpu(), want.grad) < 2e-5
+
+    lat = torch.randn(N, 2, generator=g)
+    W, b = 0.3 * torch.randn(512, 2, generator=g), 0.1 * torch.randn(512, generator=g)
+    up = torch.randn(N, 512, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (lat, W, b)]
+    (F.linear(*ref_in) * up).sum().backward()
+    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (lat, W, b)]
+    h = DecoderFc.apply(*dev_in)
+    (h * up.to(DEV)).sum().backward()
+    assert rel_err(h.detach().cpu(), F.linear(lat, W, b)) < 2e-5
+    for got, want in zip(dev_in, ref_in):
+        assert rel_err(got.grad.cpu(), want.grad) < 2e-5
+
+    B, T = 3, max(N // 3, 1)
+    a0, m0 = torch.randn(B, T, 2, generator=g), torch.randn(B, T, 2, generator=g)
+    v0 = 0.01 + 0.05 * torch.rand(B, T, 2, generator=g)
+    w = torch.randn(B, T, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (a0, m0, v0)]
+    lg = lambda x, mean, var: -0.5 * math.log(2 * math.pi) - 0.5 * torch.log(var) - (x - mean) ** 2 / (2 * var)
+    ref = (lg(ref_in[0], torch.zeros(()), torch.ones(())) - lg(*ref_in)).sum(-1)
+    (ref * w).sum().backward()
+    dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (a0, m0, v0)]
+    reg = LatentReg.apply(*dev_in)
+    (reg * w.to(DEV)).sum().backward()
+    assert rel_err(reg.detach().cpu(), ref.detach()) < 2e-5
+    for got, want in zip(dev_in, ref_in):
+        assert rel_err(got.grad.cpu(), want.grad) < 2e-5

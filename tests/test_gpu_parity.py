@@ -193,6 +193,12 @@ def test_conv_edge_gpu(N):
     parity_cases.conv_edge_vs_torch(DEV, N)
 
 
+@pytest.mark.parametrize("N", [1, 37, 12800])
+def test_vae_heads_gpu(N):
+    """Fused encoder heads + reparameterisation, decoder fc, latent regulariser vs torch."""
+    parity_cases.vae_heads_vs_torch(DEV, N)
+
+
 @pytest.mark.parametrize("N,side", [(1, 8), (2, 8), (7, 8), (1031, 8), (1, 4), (8, 4), (13, 4), (4099, 4)])
 def test_dec_up_gpu(N, side):
     """Register-stationary MFMA decoder blocks vs torch (ragged last iteration, more iterations than workgroups)."""

@@ -173,6 +173,12 @@ def test_conv_edge_hostsim(N):
     parity_cases.conv_edge_vs_torch("cpu", N)
 
 
+@pytest.mark.parametrize("N", [1, 50])
+def test_vae_heads_hostsim(N):
+    import parity_cases
+    parity_cases.vae_heads_vs_torch("cpu", N)
+
+
 @pytest.mark.parametrize("N,side", [(3, 8), (9, 4)])
 def test_dec_up_hostsim(N, side):
     import parity_cases
