@@ -60,11 +60,13 @@ __global__ __launch_bounds__(256) void k_dec_up_fwd(const float *__restrict__ x,
   };
 #pragma unroll
   for (int j = 0; j < 4; ++j) fetch1(it, j);
-  for (; it < iters; it += gridDim.x) {
+  for (int slot = 0; it < iters; it += gridDim.x, ++slot) {
+    EM_STAMP(slot, 0);
     __syncthreads();                                 // previous iteration done with xin, its image complete
 #pragma unroll
     for (int j = 0; j < 4; ++j) reinterpret_cast<float4 *>(xin)[tid + 256 * j] = pre[j];
     __syncthreads();
+    EM_STAMP(slot, 1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int gp = 32 * t + q, fl = gp / D::PF, pix = gp % D::PF, h = pix / S, w = pix % S;
@@ -100,7 +102,10 @@ __global__ __launch_bounds__(256) void k_dec_up_fwd(const float *__restrict__ x,
         for (int u = 0; u < 4; ++u) acc = KV_MFMA_F32(wreg[g * 4 + u], bw[g][u], acc);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (t == 0) EM_STAMP(slot, 2);
+      if (t == 3) EM_STAMP(slot, 4);
       if (t == 0) __syncthreads();                   // every wave has read the previous image out before it changes
+      if (t == 0) EM_STAMP(slot, 3);
       float *o = img + fl * D::YFRAME + (2 * h) * (2 * S) + 2 * w;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256) void k_dec_up_fwd(const float *__restrict__ x,
         o[c * 4 * D::PF + dy * 2 * S + dx] = fmaxf(acc[r] + bv[r], 0.f);
       }
     }
+    EM_STAMP(slot, 5);
     done_base = (uint32_t)(it * D::IT_Y) * 4u;       // frames >= N: dropped by the hardware
   }
   __syncthreads();

@@ -12,7 +12,7 @@
 
 namespace kvae {
 
-constexpr int HD_F = 512, HD_A = 2, HD_WAVES = 1024;   // partial rows = waves of the backward grids
+constexpr int HD_F = 512, HD_A = 2, HD_WAVES = 512;   // partial rows = waves of the backward grids
 
 __device__ __forceinline__ float hd_wave_sum(float v) {
 #pragma unroll

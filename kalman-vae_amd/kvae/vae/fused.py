@@ -142,8 +142,8 @@ class EncoderMid(torch.autograd.Function):
         Nb, Cc, s, _ = x.shape
         out = torch.empty(Nb, Cc, s // 2, s // 2, device=x.device, dtype=torch.float32)
         lib = N.lib_for(x)
-        lib.check(lib.dll.kvae_enc_mid_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cc, s, N.stream_for(x)),
-                  "kvae_enc_mid_fwd")
+        lib.check(N.timed(f"enc_mid_fwd_s{s}", x, lambda: lib.dll.kvae_enc_mid_fwd(
+            N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cc, s, N.stream_for(x))), "kvae_enc_mid_fwd")
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -182,8 +182,8 @@ class DecoderUp(torch.autograd.Function):
         Nb, Cin, s, _ = x.shape
         out = torch.empty(Nb, 32, 2 * s, 2 * s, device=x.device, dtype=torch.float32)
         lib = N.lib_for(x)
-        lib.check(lib.dll.kvae_dec_up_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cin, s, N.stream_for(x)),
-                  "kvae_dec_up_fwd")
+        lib.check(N.timed(f"dec_up_fwd_s{s}", x, lambda: lib.dll.kvae_dec_up_fwd(
+            N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cin, s, N.stream_for(x))), "kvae_dec_up_fwd")
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -197,8 +197,9 @@ class DecoderUp(torch.autograd.Function):
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
         bp = torch.empty(rows, 128, device=x.device, dtype=torch.float32)
-        lib.check(lib.dll.kvae_dec_up_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
-                                          N.ptr(wp), N.ptr(bp), Nb, Cin, s, N.stream_for(x)), "kvae_dec_up_bwd")
+        lib.check(N.timed(f"dec_up_bwd_s{s}", x, lambda: lib.dll.kvae_dec_up_bwd(
+            N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None, N.ptr(wp), N.ptr(bp), Nb, Cin, s,
+            N.stream_for(x))), "kvae_dec_up_bwd")
         return g_x, colsum(wp).view_as(weight), colsum(bp)
 
 

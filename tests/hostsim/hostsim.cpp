@@ -554,7 +554,7 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
 // Skinny fc ends of the VAE and the latent regulariser: plain loops, same argument checks as the HIP launchers.
 #include <math.h>
 extern "C" {
-int64_t kvae_head_partial_rows(void) { return 1024; }
+int64_t kvae_head_partial_rows(void) { return 512; }
 
 int kvae_enc_head_fwd(const float *feat, const float *Wmu, const float *bmu, const float *Wvar, const float *bvar,
                       const float *eps, float *mu, float *var, float *a, int64_t N, int32_t F, int32_t A, float ne, void *) {
