@@ -234,12 +234,24 @@ def timed(name, t, thunk):
     return rc
 
 
-def colsum(partials):
-    """out[c] = sum_r partials[r, c] in one small kernel (k_colsum): the second stage of every partial-row reduction.
-    torch's sum(0) on these shapes costs ~18 us per call and there are ~20 of them per training step."""
+def _colsum_raw(p2):
     import torch
-    p2 = partials.reshape(partials.shape[0], -1).contiguous()
     out = torch.empty(p2.shape[1], device=p2.device, dtype=torch.float32)
     lib = lib_for(p2)
     lib.check(lib.dll.kvae_colsum(ptr(p2), ptr(out), p2.shape[0], p2.shape[1], stream_for(p2)), "kvae_colsum")
-    return out.view(partials.shape[1:])
+    return out
+
+
+def colsum(partials):
+    """out[c] = sum_r partials[r, c] (k_colsum): the second stage of every partial-row reduction, and the bias
+    gradients of the recurrent networks.  Tall inputs ([B*T, cols] with few columns) are folded in two passes -
+    [R1, R2*cols] then [R2, cols] - so that the kernel always sees many columns to spread over the chip."""
+    p2 = partials.reshape(partials.shape[0], -1).contiguous()
+    rows, cols = p2.shape
+    if rows >= 1024 and cols < 4096:
+        r1 = 64
+        while r1 > 1 and rows % r1:
+            r1 //= 2
+        if r1 > 1:
+            p2 = _colsum_raw(p2.view(r1, (rows // r1) * cols)).view(rows // r1, cols)
+    return _colsum_raw(p2).view(partials.shape[1:])
