@@ -24,6 +24,10 @@ parity_cases.safe_cholesky_levels("cpu")
 parity_cases.lstm_vs_torch("cpu", 2, 5, 2, 50)
 parity_cases.regime_vs_torch("cpu", 2, 6, 3, 0.7, False)
 parity_cases.vae_epilogue_vs_torch("cpu", 2, 3, 4, 4, 2, True)
+parity_cases.conv_edge_vs_torch("cpu", 2)
+parity_cases.enc_mid_vs_torch("cpu", 2, 8)
+parity_cases.dec_up_vs_torch("cpu", 2, 4)
+parity_cases.vae_heads_vs_torch("cpu", 5)
 print("ASAN-OK")
 """
 
