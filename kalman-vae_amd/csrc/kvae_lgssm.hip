@@ -160,6 +160,12 @@ static int check_problem(const kvae_lgssm_problem *p) {
   } while (0)
 
 // kvae_lgssm_wide.hip: the same bodies with 256 threads per sequence (used when n > 8)
+#define KVAE_ELBO_TPP_MIN_STEPS 0   /* thread-per-step wins at every size measured (12.8k .. 1.6M steps), DESIGN.md */
+extern "C" void kvae_tpp_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
+                                           float *ws, int32_t *levels, hipStream_t s);
+extern "C" void kvae_tpp_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
+                                     float *terms, const int32_t *levels, const float *ws, float *g_mus, float *g_Sigs,
+                                     const kvae_lgssm_input_grads *g, int have_g, hipStream_t s);
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s);
 extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
@@ -251,11 +257,22 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(chol_levels, 0, 2 * sizeof(int32_t), s) != hipSuccess) return launch_status("memset chol_levels");
   const unsigned grid = (unsigned)((int64_t)prob->B * prob->T);
+  kvae_lgssm_input_grads gz;
+  memset(&gz, 0, sizeof(gz));
+  // n = 4: one THREAD per (b,t) (kvae_lgssm_tpp.hip); KVAE_ELBO_TPP=0 selects the wave-per-step kernels for A/B runs
+  static const int tpp_env = getenv("KVAE_ELBO_TPP") ? atoi(getenv("KVAE_ELBO_TPP")) : -1;
+  const bool n4 = prob->n == 4 && prob->m == 4 && prob->p == 2;
+  if (n4 && (tpp_env == 1 || (tpp_env < 0 && (int64_t)prob->B * prob->T >= KVAE_ELBO_TPP_MIN_STEPS))) {
+    kvae_tpp_launch_elbo_probe(prob, Sigmas_smooth, mus_smooth, eps, ws_lz, (int32_t *)chol_levels, s);
+    rc = launch_status("k_elbo_probe_tpp");
+    if (rc) return rc;
+    kvae_tpp_launch_elbo(prob, mus_smooth, Sigmas_smooth, eps, terms, (const int32_t *)chol_levels, (const float *)ws_lz, g_mus,
+                         g_Sigmas, want_g ? g : &gz, want_g ? 1 : 0, s);
+    return launch_status("k_elbo_tpp");
+  }
   KVAE_DISPATCH(*prob, k_elbo_probe<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, Sigmas_smooth, mus_smooth, eps, ws_lz, chol_levels));
   rc = launch_status("k_elbo_probe");
   if (rc) return rc;
-  kvae_lgssm_input_grads gz;
-  memset(&gz, 0, sizeof(gz));
   KVAE_DISPATCH(*prob, k_elbo<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps,
                                            terms, (const int32_t *)chol_levels, (const float *)ws_lz, g_mus, g_Sigmas, want_g ? *g : gz,
                                            want_g ? 1 : 0));

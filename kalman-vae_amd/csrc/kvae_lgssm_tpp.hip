@@ -1,0 +1,50 @@
+// kvae_lgssm_tpp.hip — the ELBO bodies (lgssm_elbo.h) built with ONE THREAD per (sequence, step) instead of one
+// wavefront: the ELBO has no recursion in t, a 4x4 problem keeps at most 16 of a wavefront's 64 lanes busy and runs its
+// triangular solves on lane 0, so at large batch the wave-per-step kernel leaves the chip idle (B = 32768, T = 50:
+// 3.7 ms = 126 GB/s algorithmic).  Here every lane owns a whole (b,t); the phase structure of the body collapses to
+// straight-line code (KV_PAR = serial loop, KV_SYNC = nothing, the ElboLds struct is thread-private), exactly the
+// form the host simulation checks against the oracle.  Separate translation unit (own namespace) because the
+// execution model is a compile-time property of the bodies.
+#define KV_TPP 1
+#define kvae kvae_tpp
+#include <hip/hip_runtime.h>
+
+#include "lgssm_elbo.h"
+
+using namespace kvae;
+
+template <class D>
+__global__ __launch_bounds__(64) void k_elbo_probe_tpp(kvae_lgssm_problem P, const float *Sig_s, const float *mus,
+                                                       const float *eps, float *ws, int32_t *levels) {
+  const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (q >= (int64_t)P.B * P.T) return;
+  ElboLds<D> L;
+  const D d(P.n, P.m, P.p);
+  const int b = (int)(q / P.T), t = (int)(q - (int64_t)b * P.T);
+  elbo_probe_body(d, P, Sig_s, mus, eps, ws, levels, b, t, L);
+}
+
+template <class D>
+__global__ __launch_bounds__(64) void k_elbo_tpp(kvae_lgssm_problem P, const float *mus, const float *Sigs, const float *eps,
+                                                 float *terms, const int32_t *levels, const float *ws, float *g_mus,
+                                                 float *g_Sigs, kvae_lgssm_input_grads G, int have_g) {
+  const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (q >= (int64_t)P.B * P.T) return;
+  ElboLds<D> L;
+  const D d(P.n, P.m, P.p);
+  const int b = (int)(q / P.T), t = (int)(q - (int64_t)b * P.T);
+  elbo_body(d, P, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, have_g ? &G : nullptr, b, t, L);
+}
+
+// launchers used by kvae_lgssm.hip (not part of the public C ABI); n = m = 4, p = 2 only
+extern "C" void kvae_tpp_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
+                                           float *ws, int32_t *levels, hipStream_t s) {
+  const unsigned grid = (unsigned)(((int64_t)p->B * p->T + 63) / 64);
+  k_elbo_probe_tpp<SDims<4, 4, 2>><<<dim3(grid), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, ws, levels);
+}
+extern "C" void kvae_tpp_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
+                                     float *terms, const int32_t *levels, const float *ws, float *g_mus, float *g_Sigs,
+                                     const kvae_lgssm_input_grads *g, int have_g, hipStream_t s) {
+  const unsigned grid = (unsigned)(((int64_t)p->B * p->T + 63) / 64);
+  k_elbo_tpp<SDims<4, 4, 2>><<<dim3(grid), dim3(64), 0, s>>>(*p, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, *g, have_g);
+}

@@ -31,6 +31,16 @@
 #define KV_LANE 0
 #define KV_SYNC() ((void)0)
 #define KV_UNROLL
+#elif defined(KV_TPP)
+// kvae_lgssm_tpp.hip: ONE THREAD per problem on the GPU — the same bodies as the host simulation (KV_PAR is a serial
+// loop, the *Lds struct is thread-private), 64 independent problems per wavefront.  For bodies without recursion in t.
+#include <hip/hip_runtime.h>
+#define KV_DEV __device__ __forceinline__
+#define KV_MEM __device__ __forceinline__
+#define KV_LANES 1
+#define KV_LANE 0
+#define KV_SYNC() ((void)0)
+#define KV_UNROLL _Pragma("unroll")
 #else
 #include <hip/hip_runtime.h>
 #define KV_DEV __device__ __forceinline__
