@@ -209,7 +209,8 @@ def main():
             ach = chain[dom]["GBps"]
             n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
             roofline = {"kernel": {"smooth_fwd": "k_smooth_fwd_n4" if n4 else "k_smooth_fwd",
-                                   "smooth_bwd": "k_smooth_bwd_n4" if n4 else "k_smooth_bwd", "elbo": "k_elbo(+probe)"}[dom],
+                                   "smooth_bwd": "k_smooth_bwd_n4" if n4 else "k_smooth_bwd",
+                                   "elbo": "k_elbo_tpp(+probe)" if n4 else "k_elbo(+probe)"}[dom],
                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom),
                         "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["avg_us"],
