@@ -15,6 +15,7 @@ struct RegimeLds {
   float Lt[KVAE_REGIME_MAX_K * KVAE_REGIME_MAX_K], P[KVAE_REGIME_MAX_K * KVAE_REGIME_MAX_K];
   float y[KVAE_REGIME_MAX_K], yp[KVAE_REGIME_MAX_K], l[KVAE_REGIME_MAX_K], g[KVAE_REGIME_MAX_K];
   float tp[KVAE_REGIME_MAX_K], ys[KVAE_REGIME_MAX_K], gy[KVAE_REGIME_MAX_K], gl[KVAE_REGIME_MAX_K], gtp[KVAE_REGIME_MAX_K];
+  float gyin[KVAE_REGIME_MAX_K];   // upstream g_y of the current step
 };
 
 // softmax / log_softmax pieces of a K-vector held in LDS, computed redundantly by the calling lane
@@ -50,13 +51,25 @@ KV_DEV void regime_fwd_body(const float *logits, const float *init_logits, const
   const int KK = K * K;
   KV_PAR(e, KK) { L.P[e] = Pm[e]; }
   KV_PAR(j, K) { L.l[j] = init_logits[(int64_t)b * K + j]; L.g[j] = gumbel[((int64_t)b * T) * K + j]; L.yp[j] = 0.f; }
+  // the inputs of step t+1 do not depend on step t: they are fetched into registers one step ahead, otherwise every
+  // step of this latency-bound chain starts with a full global-memory round trip
+  Prefetch<KVAE_REGIME_MAX_K * KVAE_REGIME_MAX_K> pf_l;
+  Prefetch<KVAE_REGIME_MAX_K> pf_g;
+  if (T > 1) {
+    pf_l.issue(logits + ((int64_t)b * T + 1) * KK, KK);
+    pf_g.issue(gumbel + ((int64_t)b * T + 1) * K, K);
+  }
   KV_SYNC();
   for (int t = 0; t < T; ++t) {
     const int64_t q = (int64_t)b * T + t;
     if (t > 0) {
-      KV_PAR(e, KK) { L.Lt[e] = logits[q * KK + e]; }
-      KV_PAR(j, K) { L.g[j] = gumbel[q * K + j]; }
+      pf_l.commit(L.Lt, KK);
+      pf_g.commit(L.g, K);
       KV_SYNC();
+      if (t + 1 < T) {
+        pf_l.issue(logits + (q + 1) * KK, KK);
+        pf_g.issue(gumbel + (q + 1) * K, K);
+      }
       KV_PAR(j, K) {  // l_t = y_{t-1}^T logits[t] ; tp = y_{t-1}^T P
         float acc = 0.f, acp = 0.f;
         for (int i = 0; i < K; ++i) {
@@ -98,17 +111,38 @@ KV_DEV void regime_bwd_body(const float *logits, const float *init_logits, const
   const int KK = K * K;
   KV_PAR(e, KK) { L.P[e] = Pm[e]; }
   KV_PAR(j, K) { L.gy[j] = 0.f; }
+  // one-step-ahead register prefetch of everything a step reads from global memory (see the forward body)
+  Prefetch<KVAE_REGIME_MAX_K * KVAE_REGIME_MAX_K> pf_l;
+  Prefetch<KVAE_REGIME_MAX_K> pf_y, pf_yp, pf_g, pf_gy;
+  float glq_n = 0.f, glp_n = 0.f;
+  auto issue = [&](int t) {
+    const int64_t q = (int64_t)b * T + t;
+    pf_y.issue(y_seq + q * K, K);
+    pf_g.issue(gumbel + q * K, K);
+    pf_gy.issue(g_y + q * K, K);
+    if (t > 0) {
+      pf_yp.issue(y_seq + (q - 1) * K, K);
+      pf_l.issue(logits + q * KK, KK);
+    }
+    glq_n = g_lq[q];
+    glp_n = g_lp[q];
+  };
+  issue(T - 1);
   KV_SYNC();
   for (int t = T - 1; t >= 0; --t) {
     const int64_t q = (int64_t)b * T + t;
-    KV_PAR(j, K) {
-      L.y[j] = y_seq[q * K + j];
-      L.yp[j] = t > 0 ? y_seq[(q - 1) * K + j] : 0.f;
-      L.g[j] = gumbel[q * K + j];
-      if (t == 0) L.l[j] = init_logits[(int64_t)b * K + j];
+    pf_y.commit(L.y, K);
+    pf_g.commit(L.g, K);
+    pf_gy.commit(L.gyin, K);
+    if (t > 0) {
+      pf_yp.commit(L.yp, K);
+      pf_l.commit(L.Lt, KK);
+    } else {
+      KV_PAR(j, K) { L.yp[j] = 0.f; L.l[j] = init_logits[(int64_t)b * K + j]; }
     }
-    if (t > 0) { KV_PAR(e, KK) { L.Lt[e] = logits[q * KK + e]; } }
+    const float glq = glq_n, glp = glp_n;
     KV_SYNC();
+    if (t > 0) issue(t - 1);
     if (t > 0) {
       KV_PAR(j, K) {
         float acc = 0.f, acp = 0.f;
@@ -121,7 +155,6 @@ KV_DEV void regime_bwd_body(const float *logits, const float *init_logits, const
       }
       KV_SYNC();
     }
-    const float glq = g_lq[q], glp = g_lp[q];
     // total adjoint of y_t, and the soft sample (needed for the softmax Jacobian)
     KV_PAR(j, K) {
       float mx, lse, mx1, lse1;
@@ -130,7 +163,7 @@ KV_DEV void regime_bwd_body(const float *logits, const float *init_logits, const
       L.ys[j] = expf((L.l[j] + L.g[j]) * inv_tau - mx) / expf(lse);
       const float lsm = (L.l[j] - mx1) - lse1;
       const float lpj = t > 0 ? logf(fmaxf(L.tp[j], 1e-8f)) : logf(1.0f / (float)K);
-      L.gy[j] = L.gy[j] + g_y[q * K + j] + glq * lsm + glp * lpj;   // same lane reads and writes gy[j]
+      L.gy[j] = L.gy[j] + L.gyin[j] + glq * lsm + glp * lpj;   // same lane reads and writes gy[j]
     }
     KV_SYNC();
     KV_PAR(j, K) {
