@@ -52,7 +52,11 @@
 #define KV_SYNC() __syncthreads()
 #define KV_UNROLL _Pragma("unroll")
 #endif
+#if defined(KV_TPP)   // serial loops with compile-time bounds: unroll so that the thread-private state becomes registers
+#define KV_PAR(e, count) _Pragma("unroll") for (int e = 0; e < (count); ++e)
+#else
 #define KV_PAR(e, count) for (int e = KV_LANE; e < (count); e += KV_LANES)
+#endif
 #define KV_LANE0 if (KV_LANE == 0)
 #define KV_PF_SLOTS(CNT) (((CNT) + KV_LANES - 1) / KV_LANES)
 
