@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lgssm_elbo.h"
+#include "regime.h"
 
 using namespace kvae;
 
@@ -47,4 +48,53 @@ extern "C" void kvae_tpp_launch_elbo(const kvae_lgssm_problem *p, const float *m
                                      const kvae_lgssm_input_grads *g, int have_g, hipStream_t s) {
   const unsigned grid = (unsigned)(((int64_t)p->B * p->T + 63) / 64);
   k_elbo_tpp<SDims<4, 4, 2>><<<dim3(grid), dim3(64), 0, s>>>(*p, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, *g, have_g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Regime chain (regime.h) with one thread per SEQUENCE and the regime count K a compile-time constant: the K x K work
+// of a step is a few dozen flops, so a wavefront per sequence spends its time in LDS round trips and wave syncs
+// (119 us forward / 167 us backward at B = 256, T = 50, K = 3); a single lane walks the T steps in registers.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(64) void k_regime_fwd_tpp(const float *logits, const float *init_logits, const float *gumbel,
+                                                       const float *P, float *y_seq, float *log_q, float *log_p, int B, int T,
+                                                       float tau, int hard) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  RegimeLds L;
+  regime_fwd_body(logits, init_logits, gumbel, P, y_seq, log_q, log_p, b, T, KC, tau, hard, L);
+}
+template <int KC>
+__global__ __launch_bounds__(64) void k_regime_bwd_tpp(const float *logits, const float *init_logits, const float *gumbel,
+                                                       const float *P, const float *y_seq, const float *g_y, const float *g_lq,
+                                                       const float *g_lp, float *g_logits, float *g_init, int B, int T, float tau) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  RegimeLds L;
+  regime_bwd_body(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, b, T, KC, tau, L);
+}
+
+#define KVAE_REGIME_TPP_CASES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+// return 1 if a thread-per-sequence instance exists for K (and was launched), 0 otherwise
+extern "C" int kvae_tpp_launch_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                                          float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau, int hard,
+                                          hipStream_t s) {
+  const dim3 grid((unsigned)((B + 63) / 64));
+  switch (K) {
+#define X(KC) case KC: k_regime_fwd_tpp<KC><<<grid, dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, tau, hard); return 1;
+    KVAE_REGIME_TPP_CASES(X)
+#undef X
+    default: return 0;
+  }
+}
+extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                                          const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
+                                          float *g_logits, float *g_init, int B, int T, int K, float tau, hipStream_t s) {
+  const dim3 grid((unsigned)((B + 63) / 64));
+  switch (K) {
+#define X(KC) case KC: k_regime_bwd_tpp<KC><<<grid, dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, B, T, tau); return 1;
+    KVAE_REGIME_TPP_CASES(X)
+#undef X
+    default: return 0;
+  }
 }
