@@ -11,6 +11,14 @@ from .. import _native as N
 colsum = N.colsum
 
 
+def _chunks(n, size):
+    return [(a, min(a + size, n)) for a in range(0, n, size)]
+
+
+def _acc(total, part):
+    return part if total is None else total + part
+
+
 class BiasShuffleAct(torch.autograd.Function):
     """out[N,C,H*r,W*r] = act(pixel_shuffle_r(x[N,C*r*r,H,W] + bias))."""
 
@@ -134,7 +142,9 @@ class EncoderMid(torch.autograd.Function):
     def supported(x, conv):
         return (x.dim() == 4 and x.shape[1] == 32 and x.shape[2] == x.shape[3] and x.shape[2] in (16, 8)
                 and tuple(conv.weight.shape) == (32, 32, 3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
-                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and x.shape[0] <= 30000)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None)
+
+    CHUNK = 16384   # frames per launch: a launch addresses its tensors with 32-bit byte offsets (C ABI: KVAE_ERR_ARG beyond)
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -142,8 +152,9 @@ class EncoderMid(torch.autograd.Function):
         Nb, Cc, s, _ = x.shape
         out = torch.empty(Nb, Cc, s // 2, s // 2, device=x.device, dtype=torch.float32)
         lib = N.lib_for(x)
-        lib.check(N.timed(f"enc_mid_fwd_s{s}", x, lambda: lib.dll.kvae_enc_mid_fwd(
-            N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cc, s, N.stream_for(x))), "kvae_enc_mid_fwd")
+        for a, b in _chunks(Nb, EncoderMid.CHUNK):
+            lib.check(N.timed(f"enc_mid_fwd_s{s}", x, lambda: lib.dll.kvae_enc_mid_fwd(
+                N.ptr(x[a:b]), N.ptr(weight), N.ptr(bias), N.ptr(out[a:b]), b - a, Cc, s, N.stream_for(x))), "kvae_enc_mid_fwd")
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -153,13 +164,17 @@ class EncoderMid(torch.autograd.Function):
         g = g.contiguous()
         Nb, Cc, s, _ = x.shape
         lib = N.lib_for(x)
-        rows = lib.dll.kvae_enc_mid_partial_rows(Nb, s)
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
-        bp = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
-        lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None,
-                                           N.ptr(wp), N.ptr(bp), Nb, Cc, s, N.stream_for(x)), "kvae_enc_mid_bwd")
-        return g_x, colsum(wp).view_as(weight), colsum(bp)
+        gw = gb = None
+        for a, b in _chunks(Nb, EncoderMid.CHUNK):
+            rows = lib.dll.kvae_enc_mid_partial_rows(b - a, s)
+            wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
+            bp = torch.empty(rows, Cc, device=x.device, dtype=torch.float32)
+            lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x[a:b]), N.ptr(weight), N.ptr(out[a:b]), N.ptr(g[a:b]),
+                                               N.ptr(g_x[a:b]) if g_x is not None else None, N.ptr(wp), N.ptr(bp), b - a, Cc, s,
+                                               N.stream_for(x)), "kvae_enc_mid_bwd")
+            gw, gb = _acc(gw, colsum(wp)), _acc(gb, colsum(bp))
+        return g_x, gw.view_as(weight), gb
 
 
 class DecoderUp(torch.autograd.Function):
@@ -167,14 +182,13 @@ class DecoderUp(torch.autograd.Function):
     exact-f32 matrix cores with the weights stationary in registers (csrc/vae_conv_up.h; reference kvae/vae/vae.py:92-101).
     Bias, PixelShuffle and ReLU are part of the kernels in both directions."""
 
-    MAX_FRAMES = 60000   # one launch addresses its tensors with 32-bit byte offsets
+    CHUNK = 16384   # frames per launch (32-bit byte offsets inside a launch)
 
     @staticmethod
     def supported(x, conv):
         return (x.dim() == 4 and x.shape[1] == 32 and x.shape[2] == x.shape[3] and x.shape[2] in (8, 4)
                 and tuple(conv.weight.shape) == (128, 32, 3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
-                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
-                and x.shape[0] <= DecoderUp.MAX_FRAMES)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None)
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -182,8 +196,9 @@ class DecoderUp(torch.autograd.Function):
         Nb, Cin, s, _ = x.shape
         out = torch.empty(Nb, 32, 2 * s, 2 * s, device=x.device, dtype=torch.float32)
         lib = N.lib_for(x)
-        lib.check(N.timed(f"dec_up_fwd_s{s}", x, lambda: lib.dll.kvae_dec_up_fwd(
-            N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cin, s, N.stream_for(x))), "kvae_dec_up_fwd")
+        for a, b in _chunks(Nb, DecoderUp.CHUNK):
+            lib.check(N.timed(f"dec_up_fwd_s{s}", x, lambda: lib.dll.kvae_dec_up_fwd(
+                N.ptr(x[a:b]), N.ptr(weight), N.ptr(bias), N.ptr(out[a:b]), b - a, Cin, s, N.stream_for(x))), "kvae_dec_up_fwd")
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -193,14 +208,17 @@ class DecoderUp(torch.autograd.Function):
         g = g.contiguous()
         Nb, Cin, s, _ = x.shape
         lib = N.lib_for(x)
-        rows = lib.dll.kvae_dec_up_partial_rows(Nb, s)
         g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
-        bp = torch.empty(rows, 128, device=x.device, dtype=torch.float32)
-        lib.check(N.timed(f"dec_up_bwd_s{s}", x, lambda: lib.dll.kvae_dec_up_bwd(
-            N.ptr(x), N.ptr(weight), N.ptr(out), N.ptr(g), N.ptr(g_x) if g_x is not None else None, N.ptr(wp), N.ptr(bp), Nb, Cin, s,
-            N.stream_for(x))), "kvae_dec_up_bwd")
-        return g_x, colsum(wp).view_as(weight), colsum(bp)
+        gw = gb = None
+        for a, b in _chunks(Nb, DecoderUp.CHUNK):
+            rows = lib.dll.kvae_dec_up_partial_rows(b - a, s)
+            wp = torch.empty(rows, weight.numel(), device=x.device, dtype=torch.float32)
+            bp = torch.empty(rows, 128, device=x.device, dtype=torch.float32)
+            lib.check(N.timed(f"dec_up_bwd_s{s}", x, lambda: lib.dll.kvae_dec_up_bwd(
+                N.ptr(x[a:b]), N.ptr(weight), N.ptr(out[a:b]), N.ptr(g[a:b]), N.ptr(g_x[a:b]) if g_x is not None else None, N.ptr(wp),
+                N.ptr(bp), b - a, Cin, s, N.stream_for(x))), "kvae_dec_up_bwd")
+            gw, gb = _acc(gw, colsum(wp)), _acc(gb, colsum(bp))
+        return g_x, gw.view_as(weight), gb
 
 
 def _optr(t):

@@ -205,6 +205,43 @@ def test_dec_up_gpu(N, side):
     parity_cases.dec_up_vs_torch(DEV, N, side)
 
 
+@pytest.mark.parametrize("which,side", [("enc_mid", 8), ("dec_up", 4)])
+def test_conv_chunked_launches_gpu(which, side, monkeypatch):
+    """20000 frames = two launches (CHUNK = 16384).  They must equal ONE launch over all frames and five independent
+    4000-frame calls (a size the kernels are checked at against the CPU above): outputs and data gradients bit-identical,
+    weight gradients to fp32 summation order.  No external reference at this size: torch's CPU convolution backward
+    (fp32 and fp64 disagree with each other above 16384 frames) and MIOpen's Winograd data gradient (8e-3 off) both
+    proved unreliable here, while the three ways of running our kernels agree."""
+    from kvae.vae.fused import DecoderUp, EncoderMid
+    Fn = EncoderMid if which == "enc_mid" else DecoderUp
+    N, co = 20000, (32 if which == "enc_mid" else 128)
+    g = torch.Generator().manual_seed(7)
+    x = torch.relu(torch.randn(N, 32, side, side, generator=g)).to(DEV)
+    W = (0.08 * torch.randn(co, 32, 3, 3, generator=g)).to(DEV)
+    b = (0.1 * torch.randn(co, generator=g)).to(DEV)
+    o_side = side // 2 if which == "enc_mid" else 2 * side
+    up = torch.linspace(-1, 1, N * 32 * o_side * o_side, device=DEV).view(N, 32, o_side, o_side)
+
+    def run(slices):
+        Ws, bs = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        outs, gxs = [], []
+        for lo, hi in slices:
+            xs = x[lo:hi].clone().requires_grad_(True)
+            out = Fn.apply(xs, Ws, bs)
+            (out * up[lo:hi]).sum().backward()
+            outs.append(out.detach())
+            gxs.append(xs.grad)
+        return torch.cat(outs), torch.cat(gxs), Ws.grad, bs.grad
+    chunked = run([(0, N)])
+    pieces = run([(i, i + 4000) for i in range(0, N, 4000)])
+    monkeypatch.setattr(Fn, "CHUNK", 1 << 30)
+    single = run([(0, N)])
+    for other in (single, pieces):
+        assert torch.equal(chunked[0], other[0]) and torch.equal(chunked[1], other[1])
+        for a, r in zip(chunked[2:], other[2:]):
+            assert rel_err(a.cpu(), r.cpu()) < 1e-4   # fp32 summation order over 3e5 cancelling terms
+
+
 @pytest.mark.parametrize("N,side", [(1, 16), (2, 16), (7, 16), (1031, 16), (1, 8), (8, 8), (13, 8), (4099, 8)])
 def test_enc_mid_gpu(N, side):
     """MFMA stride-2 encoder layers vs torch; odd frame counts exercise the ragged last iteration, the large ones the

@@ -185,6 +185,16 @@ def test_dec_up_hostsim(N, side):
     parity_cases.dec_up_vs_torch("cpu", N, side)
 
 
+def test_conv_chunked_launches_hostsim(monkeypatch):
+    """Frame counts above CHUNK are split into several launches whose weight gradients are summed."""
+    import parity_cases
+    from kvae.vae.fused import DecoderUp, EncoderMid
+    monkeypatch.setattr(EncoderMid, "CHUNK", 2)
+    monkeypatch.setattr(DecoderUp, "CHUNK", 3)
+    parity_cases.enc_mid_vs_torch("cpu", 5, 8)
+    parity_cases.dec_up_vs_torch("cpu", 7, 4)
+
+
 @pytest.mark.parametrize("N,side", [(3, 16), (9, 8)])
 def test_enc_mid_hostsim(N, side):
     import parity_cases
