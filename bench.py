@@ -49,7 +49,8 @@ def build_model(args, dev):
     from kvae.model.model import KVAE
     from kvae.utils.config import KVAEConfig
     torch.manual_seed(0)   # identical replicas on every rank
-    cfg = KVAEConfig(dynamics_model=args.dynamics, num_modes=args.modes, z_dim=args.z_dim, a_dim=2)
+    cfg = KVAEConfig(dynamics_model=args.dynamics, num_modes=args.modes, z_dim=args.z_dim, a_dim=2,
+                     u_dim=args.z_dim if args.z_dim != 4 else 4)   # configs[4] (C5): z = u = 16
     model = KVAE(cfg)
     with torch.no_grad():  # spread the K modes so the alpha-net / mixing path carries real gradients
         model.kalman_filter.dyn_params.A.add_(0.05 * torch.randn_like(model.kalman_filter.dyn_params.A))
