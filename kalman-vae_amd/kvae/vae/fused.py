@@ -1,8 +1,11 @@
-"""Fused conv epilogues of the frame VAE (HIP kernels k_vae_epilogue_fwd/bwd, csrc/vae_epilogue.h).
+"""HIP-backed pieces of the frame VAE (autograd Functions over the C ABI in include/kvae_lgssm.h).
 
-The convolutions themselves stay on MIOpen; what PyTorch would run after each of them as separate
-full-tensor passes (bias add, nn.PixelShuffle, nn.ReLU — reference kvae/vae/vae.py:20-31, 92-101) is one
-pass forward and one pass backward here."""
+  * EncoderStem / EncoderMid / DecoderUp / DecoderHead - the convolutions of the reference's default encoder and decoder
+    (kvae/vae/vae.py:20-31, 92-104) with bias, ReLU and PixelShuffle fused (csrc/vae_conv_edge.h, vae_conv_mid.h, vae_conv_up.h);
+  * EncoderHead / DecoderFc / LatentReg / BernoulliFrameLogLik - the fully-connected ends, the reparameterisation and the
+    two loss terms (csrc/vae_heads.h, vae_loss.h);
+  * BiasShuffleAct / conv_block - for any OTHER convolution shape: the library convolution followed by ONE fused
+    bias + PixelShuffle + ReLU pass instead of three (csrc/vae_epilogue.h)."""
 import torch
 
 from .. import _native as N

@@ -1,6 +1,7 @@
-"""Conv VAE encoder / decoder of the KVAE.  These run on PyTorch-ROCm (MIOpen convolutions) by
-design — the north-star scope keeps them out of the hand-written HIP path — and are re-declared
-here only so that state_dict keys and shapes match the reference (kvae/vae/vae.py:11-116):
+"""Conv VAE encoder / decoder of the KVAE, re-declared so that state_dict keys and shapes match the reference
+(kvae/vae/vae.py:11-116).  On a HIP device with the reference's default shapes every layer runs on the hand-written
+kernels behind kvae.vae.fused (csrc/vae_conv_edge.h, vae_conv_mid.h, vae_conv_up.h, vae_heads.h); any other shape takes
+MIOpen for the convolution plus one fused bias/PixelShuffle/ReLU pass; host tensors take plain PyTorch:
     encoder.conv_layers.{0,2,4}, encoder.fc_mu, encoder.fc_var.0, decoder.fc, decoder.deconv_layers.{0,3,6}
 """
 import os
