@@ -51,33 +51,41 @@ __device__ __forceinline__ void dh_store_interior(float *tile, int i, const floa
   d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 }
 
+// The frame sits in LDS as a plain 32 x 16 x 16 copy (32 KiB: five workgroups per CU instead of three with a halo, and
+// the staging is eight ds_write_b128 per thread).  The zero padding comes from the out-of-range trick of vae_conv_mid.h:
+// border lanes take a base far outside the LDS allocation for the taps that fall off the frame, where DS reads return 0.
 __global__ __launch_bounds__(256) void k_dec_head_fwd(const float *__restrict__ in, const float *__restrict__ scratch,
                                                       const float *__restrict__ bias, float *__restrict__ logits) {
-  __shared__ float tile[DH_CI * DH_CS];
+  __shared__ float tile[DH_CI * 256];
   const int64_t n = blockIdx.x;
   const float4 *src = reinterpret_cast<const float4 *>(in + n * DH_CI * 256);
   float4 pre[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) pre[j] = src[threadIdx.x + 256 * j];
-  dh_zero_halo(tile, DH_CI);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dh_store_interior(tile, threadIdx.x + 256 * j, pre[j]);
+  for (int j = 0; j < 8; ++j) reinterpret_cast<float4 *>(tile)[threadIdx.x + 256 * j] = pre[j];
   __syncthreads();
   const int h = threadIdx.x >> 4, w = threadIdx.x & 15;
+  constexpr int OOB = 1 << 24;                       // float index 64 MiB past the start of LDS
+  const int tb = (h - 1) * 16 + (w - 1);
+  int base[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap % 3;
+    const bool z = (ky == 0 && h == 0) || (ky == 2 && h == 15) || (kx == 0 && w == 0) || (kx == 2 && w == 15);
+    base[tap] = (z ? OOB : tb) + ky * 16 + kx;
+  }
   kv_f2 a01 = {bias[0], bias[1]}, a23 = {bias[2], bias[3]};
   const kv_f4 *Wf = reinterpret_cast<const kv_f4 *>(scratch);
 #pragma unroll 4
   for (int ci = 0; ci < DH_CI; ++ci) {
-    const float *t = tile + ci * DH_CS + h * DH_TS + w;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const float v = t[ky * DH_TS + kx];
-        const kv_f4 wv = Wf[ci * 9 + ky * 3 + kx];
-        a01 += wv.xy * v;
-        a23 += wv.zw * v;
-      }
+    for (int tap = 0; tap < 9; ++tap) {
+      const float v = tile[base[tap] + ci * 256];
+      const kv_f4 wv = Wf[ci * 9 + tap];
+      a01 += wv.xy * v;
+      a23 += wv.zw * v;
+    }
   }
   float *o = logits + n * 1024 + (2 * h) * 32 + 2 * w;          // co = 2*dy + dx -> pixel (2h+dy, 2w+dx)
   *reinterpret_cast<float2 *>(o) = make_float2(a01.x, a01.y);
