@@ -698,7 +698,7 @@ int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_fram
 
 #include "vae_conv_edge.h"
 extern "C" {
-int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 768 ? (N < 1 ? 1 : N) : 768; }
+int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 1024 ? (N < 1 ? 1 : N) : 1024; }   // four workgroups per CU
 
 int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, float *w_scratch, int64_t N,
                       int32_t Cin, int32_t side, void *stream) {

@@ -136,8 +136,13 @@ __global__ __launch_bounds__(256) void k_dec_head_bwd_data(const float *__restri
 // frame is fetched into registers while the current one is being reduced out of LDS.
 __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ in, const float *__restrict__ g_logits,
                                                       float *__restrict__ partial, float *__restrict__ partial_b, int64_t N) {
-  __shared__ float tile[DH_CI * DH_CS];
-  __shared__ float gt[DH_CO * 256];
+  // frame copy with the channel planes padded by one float (32 lanes on 32 channels -> 32 banks), no halo: the rows
+  // above / below the frame are read from outside the LDS allocation (-> 0), the columns left / right of it are
+  // compile-time zeros of the sliding window.  9248 floats = 37 KiB: four workgroups per CU.
+  constexpr int CS = 257, OOB = 1 << 24;
+  __shared__ float lds[DH_CI * CS + DH_CO * 256];
+  __shared__ float redb[8 * DH_CO];
+  float *tile = lds, *gt = lds + DH_CI * CS;
   const int ci = threadIdx.x & 31, grp = threadIdx.x >> 5;
   kv_f2 acc[DH_CO / 2][9];
   float accb[DH_CO];
@@ -147,7 +152,6 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
     for (int k = 0; k < 9; ++k) acc[c][k] = kv_f2{0.f, 0.f};
 #pragma unroll
   for (int co = 0; co < DH_CO; ++co) accb[co] = 0.f;
-  dh_zero_halo(tile, DH_CI);
   float4 pre[8];
   float gp[4];
   int64_t n = blockIdx.x;
@@ -161,7 +165,11 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   for (; n < N; n += gridDim.x) {
     __syncthreads();                                  // previous frame's tile fully consumed
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dh_store_interior(tile, threadIdx.x + 256 * j, pre[j]);
+    for (int j = 0; j < 8; ++j) {
+      const int e = (threadIdx.x + 256 * j) * 4;
+      float *d = tile + (e >> 8) * CS + (e & 255);
+      d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = threadIdx.x + 256 * j, oh = i >> 5, ow = i & 31, co = (oh & 1) * 2 + (ow & 1);
@@ -176,25 +184,41 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
 #pragma unroll
       for (int j = 0; j < 4; ++j) gp[j] = g_logits[nn * 1024 + threadIdx.x + 256 * j];
     }
-#pragma unroll 2
-    for (int i = 0; i < 32; ++i) {
-      const int hw = grp * 32 + i, h = hw >> 4, w = hw & 15;
-      const kv_f2 g01 = {gt[hw], gt[256 + hw]}, g23 = {gt[512 + hw], gt[768 + hw]};
-      accb[0] += g01.x; accb[1] += g01.y; accb[2] += g23.x; accb[3] += g23.y;
-      const float *t = tile + ci * DH_CS + h * DH_TS + w;
+    // this thread's 32 pixels are rows 2*grp and 2*grp+1; a 3x3 window slides along each row, so a pixel costs three
+    // new input reads (its right-hand column) instead of nine
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+    for (int rr = 0; rr < 2; ++rr) {                  // fully unrolled on purpose: 234 VGPRs / 2 workgroups per CU beat
+      const int h = 2 * grp + rr;                     // the 128-VGPR / 4-per-CU build (148 vs 175 us)
+      int rb[3];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float v = t[ky * DH_TS + kx];
-          acc[0][ky * 3 + kx] += g01 * v;
-          acc[1][ky * 3 + kx] += g23 * v;
+      for (int ky = 0; ky < 3; ++ky) {
+        const bool off = (ky == 0 && rr == 0 && grp == 0) || (ky == 2 && rr == 1 && grp == 7);
+        rb[ky] = (off ? OOB : ci * CS) + (h + ky - 1) * 16;
+      }
+      float c0[3] = {0.f, 0.f, 0.f}, c1[3], c2[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) c1[ky] = tile[rb[ky]];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) c2[ky] = w + 1 < 16 ? tile[rb[ky] + w + 1] : 0.f;
+        const int hw = h * 16 + w;
+        const kv_f2 g01 = {gt[hw], gt[256 + hw]}, g23 = {gt[512 + hw], gt[768 + hw]};
+        accb[0] += g01.x; accb[1] += g01.y; accb[2] += g23.x; accb[3] += g23.y;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          acc[0][ky * 3 + 0] += g01 * c0[ky]; acc[1][ky * 3 + 0] += g23 * c0[ky];
+          acc[0][ky * 3 + 1] += g01 * c1[ky]; acc[1][ky * 3 + 1] += g23 * c1[ky];
+          acc[0][ky * 3 + 2] += g01 * c2[ky]; acc[1][ky * 3 + 2] += g23 * c2[ky];
+          c0[ky] = c1[ky];
+          c1[ky] = c2[ky];
         }
+      }
     }
   }
   __syncthreads();
-  // reduce the 8 pixel groups through LDS (reuse tile: 8 * 32 * 36 floats = 9216 <= 10400)
-  float *red = tile;
+  // reduce the 8 pixel groups through LDS (reuse the frame buffers: 8 * 32 * 36 floats = 9216 <= 9248)
+  float *red = lds;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     float *r = red + (grp * 32 + ci) * 36 + k;
@@ -202,7 +226,7 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   }
   if (ci == 0) {
 #pragma unroll
-    for (int co = 0; co < DH_CO; ++co) gt[grp * 4 + co] = accb[co];
+    for (int co = 0; co < DH_CO; ++co) redb[grp * 4 + co] = accb[co];
   }
   __syncthreads();
   for (int o = threadIdx.x; o < DH_W; o += 256) {
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   }
   if (threadIdx.x < DH_CO) {
     float s = 0.f;
-    for (int gq = 0; gq < 8; ++gq) s += gt[gq * 4 + threadIdx.x];
+    for (int gq = 0; gq < 8; ++gq) s += redb[gq * 4 + threadIdx.x];
     partial_b[(int64_t)blockIdx.x * DH_CO + threadIdx.x] = s;
   }
 }

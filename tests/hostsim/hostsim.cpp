@@ -313,7 +313,7 @@ extern "C" int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *, const kv
 
 // Direct convolutions of the VAE's thin layers: plain loops with the same argument checks as the HIP launchers.
 extern "C" {
-int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 768 ? (N < 1 ? 1 : N) : 768; }
+int64_t kvae_conv_edge_partial_rows(int64_t N) { return N < 1024 ? (N < 1 ? 1 : N) : 1024; }
 
 int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float *logits, float *w_scratch, int64_t N,
                       int32_t Cin, int32_t side, void *) {
