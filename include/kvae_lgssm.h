@@ -284,6 +284,16 @@ int kvae_latent_reg_fwd(const float *a, const float *mu, const float *var, float
 int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const float *g, float *g_a, float *g_mu,
                         float *g_var, int64_t N, int32_t A, void *stream);
 
+/* The scalar head of the objective (kvae/vae/losses.py:45-69, kvae/model/model.py:214-232) over n = B*T frames:
+ * recon = sum(lpx*mk)/denom, reg = sum(regf*mk)/denom, denom = max(sum mk, 1) (mask NULL = all ones);
+ * out6 = (loss, elbo_total, elbo_kf, vae_elbo, recon, reg), loss = -(vae_weight*(scale*recon + beta*reg) + kf_weight*elbo_kf);
+ * coef2 = per-frame d loss/d lpx, d loss/d regf (for the backward).  elbo_kf, beta: device scalars. */
+int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, const float *elbo_kf, const float *beta,
+                       float scale_reconstruction, float vae_weight, float kf_weight, float *out6, float *coef2, int64_t n,
+                       void *stream);
+int kvae_loss_head_bwd(const float *g_loss, const float *coef2, const float *mask, float kf_weight, float *g_lpx, float *g_regf,
+                       float *g_elbo_kf, int64_t n, void *stream);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 int kvae_abi_version(void);
 const char *kvae_last_error(void); /* text of the last KVAE_ERR_LAUNCH on this thread */

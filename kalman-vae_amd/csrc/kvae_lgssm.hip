@@ -867,4 +867,21 @@ int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const
   k_latent_reg_bwd<<<dim3(epi_grid(N * A)), dim3(256), 0, (hipStream_t)stream>>>(a, mu, var, g, g_a, g_mu, g_var, N, A);
   return launch_status("k_latent_reg_bwd");
 }
+int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, const float *elbo_kf, const float *beta,
+                       float scale_reconstruction, float vae_weight, float kf_weight, float *out6, float *coef2, int64_t n,
+                       void *stream) {
+  if (!lpx || !regf || !elbo_kf || !beta || !out6 || !coef2) return KVAE_ERR_NULL;
+  if (n < 1) return KVAE_ERR_ARG;
+  k_loss_head_fwd<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(lpx, regf, mask, elbo_kf, beta, scale_reconstruction, vae_weight,
+                                                                  kf_weight, out6, coef2, n);
+  return launch_status("k_loss_head_fwd");
+}
+int kvae_loss_head_bwd(const float *g_loss, const float *coef2, const float *mask, float kf_weight, float *g_lpx, float *g_regf,
+                       float *g_elbo_kf, int64_t n, void *stream) {
+  if (!g_loss || !coef2 || !g_lpx || !g_regf || !g_elbo_kf) return KVAE_ERR_NULL;
+  if (n < 1) return KVAE_ERR_ARG;
+  k_loss_head_bwd<<<dim3(epi_grid(n)), dim3(256), 0, (hipStream_t)stream>>>(g_loss, coef2, mask, kf_weight, g_lpx, g_regf,
+                                                                            g_elbo_kf, n);
+  return launch_status("k_loss_head_bwd");
+}
 }  // extern "C"

@@ -187,4 +187,64 @@ __global__ __launch_bounds__(256) void k_latent_reg_bwd(const float *__restrict_
   }
 }
 
+// The scalar head of the objective (reference kvae/vae/losses.py:45-69 and kvae/model/model.py:214-232) in ONE launch:
+//   recon = sum(lpx * mk) / denom, reg = sum(regf * mk) / denom, denom = max(sum mk, 1)
+//   vae_elbo = scale * recon + beta * reg;  elbo_total = vae_w * vae_elbo + kf_w * elbo_kf;  loss = -elbo_total
+// out[6] = (loss, elbo_total, elbo_kf, vae_elbo, recon, reg); coef[2] = d loss / d lpx, d loss / d regf per observed frame.
+// As torch ops this is ~25 dependent launches of a few microseconds each (and ~17 more in the backward), all on the
+// critical path between the decoder's forward and backward.
+__global__ __launch_bounds__(1024) void k_loss_head_fwd(const float *__restrict__ lpx, const float *__restrict__ regf,
+                                                        const float *__restrict__ mask, const float *__restrict__ elbo_kf,
+                                                        const float *__restrict__ beta, float scale, float vae_w, float kf_w,
+                                                        float *__restrict__ out, float *__restrict__ coef, int64_t n) {
+  // one block of 1024 threads, dwordx4 loads: a handful of memory round trips in total (a narrower block turns the
+  // reduction into a 50-deep chain of dependent global loads, slower than the launches it replaces)
+  __shared__ float red[3][1024];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const int64_t n4 = ((n & 3) == 0 && ((((uintptr_t)lpx | (uintptr_t)regf | (uintptr_t)mask) & 15) == 0)) ? n / 4 : 0;
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    const float4 a = reinterpret_cast<const float4 *>(lpx)[i], b = reinterpret_cast<const float4 *>(regf)[i];
+    const float4 m = mask ? reinterpret_cast<const float4 *>(mask)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+    s0 += (a.x * m.x + a.y * m.y) + (a.z * m.z + a.w * m.w);
+    s1 += (b.x * m.x + b.y * m.y) + (b.z * m.z + b.w * m.w);
+    s2 += (m.x + m.y) + (m.z + m.w);
+  }
+  for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) {
+    const float mk = mask ? mask[i] : 1.f;
+    s0 = fmaf(lpx[i], mk, s0);
+    s1 = fmaf(regf[i], mk, s1);
+    s2 += mk;
+  }
+  red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+      red[2][threadIdx.x] += red[2][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float denom = fmaxf(red[2][0], 1.f), b = beta[0], kf = elbo_kf[0];
+    const float recon = red[0][0] / denom, reg = red[1][0] / denom;
+    const float vae = scale * recon + b * reg, tot = vae_w * vae + kf_w * kf;
+    out[0] = -tot; out[1] = tot; out[2] = kf; out[3] = vae; out[4] = recon; out[5] = reg;
+    coef[0] = -vae_w * scale / denom;
+    coef[1] = -vae_w * b / denom;
+  }
+}
+// g_lpx = g * coef[0] * mk, g_regf = g * coef[1] * mk, g_kf = -kf_w * g   (g = upstream gradient of the loss)
+__global__ __launch_bounds__(256) void k_loss_head_bwd(const float *__restrict__ g, const float *__restrict__ coef,
+                                                       const float *__restrict__ mask, float kf_w, float *__restrict__ g_lpx,
+                                                       float *__restrict__ g_regf, float *__restrict__ g_kf, int64_t n) {
+  const float gg = g[0], c0 = gg * coef[0], c1 = gg * coef[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float mk = mask ? mask[i] : 1.f;
+    g_lpx[i] = c0 * mk;
+    g_regf[i] = c1 * mk;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_kf[0] = -kf_w * gg;
+}
+
 }  // namespace kvae

@@ -52,7 +52,7 @@ SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_filter_fwd", "kvae_lgssm_
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
            "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows",
            "kvae_enc_head_fwd", "kvae_enc_head_bwd", "kvae_dec_fc_fwd", "kvae_dec_fc_bwd", "kvae_head_partial_rows",
-           "kvae_latent_reg_fwd", "kvae_latent_reg_bwd",
+           "kvae_latent_reg_fwd", "kvae_latent_reg_bwd", "kvae_loss_head_fwd", "kvae_loss_head_bwd",
            "kvae_abi_version",
            "kvae_last_error", "kvae_build_info")
 
@@ -135,6 +135,10 @@ class LgssmLib:
         d.kvae_latent_reg_fwd.restype = C.c_int
         d.kvae_latent_reg_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, vp]
         d.kvae_latent_reg_bwd.restype = C.c_int
+        d.kvae_loss_head_fwd.argtypes = [vp] * 5 + [C.c_float] * 3 + [vp, vp, C.c_int64, vp]
+        d.kvae_loss_head_fwd.restype = C.c_int
+        d.kvae_loss_head_bwd.argtypes = [vp, vp, vp, C.c_float, vp, vp, vp, C.c_int64, vp]
+        d.kvae_loss_head_bwd.restype = C.c_int
         d.kvae_dec_up_partial_rows.restype = C.c_int64
         d.kvae_enc_mid_partial_rows.restype = C.c_int64
         d.kvae_conv_edge_partial_rows.argtypes = [C.c_int64]

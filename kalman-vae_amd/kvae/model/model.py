@@ -114,23 +114,48 @@ class KVAE(nn.Module):
         if u is None:
             u = torch.zeros(B, T, self.u_dim, device=x.device, dtype=x.dtype)
         x_mu = outputs["x_logits"] if outputs.get("x_logits") is not None else outputs["x_recon"]
-        x_var = torch.tensor(self.config.noise_pixel_var, device=x.device, dtype=x_mu.dtype) \
-            if self.config.out_distr.lower() != "bernoulli" else None
-        vae_elbo, recon, reg = vae_loss(x, x_mu, x_var, a, a_mu, a_var,
-                                        scale_reconstruction=self.config.scale_reconstruction, mask=mask,
-                                        out_distr=self.config.out_distr, beta=self.beta)
         side = self.lgssm_stream if (self.training and a.is_cuda) else None
-        if side is not None:
+
+        def kf_elbo():
+            if side is None:
+                return self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u, A_list, B_list, C_list,
+                                               mask=mask)
             with torch.cuda.stream(side):
-                elbo_kf = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u,
-                                                  A_list, B_list, C_list, mask=mask)
+                v = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u, A_list, B_list, C_list,
+                                            mask=mask)
             torch.cuda.current_stream().wait_stream(side)   # join before the two ELBOs are combined
+            return v
+
+        from kvae import _native
+        import os
+        head = os.environ.get("KVAE_LOSS_HEAD")
+        if ((head == "1" or (head is None and side is None)) and self.config.out_distr.lower() == "bernoulli"
+                and _native.fused_ok(x_mu) and x_mu.dtype == torch.float32
+                and x.dtype == torch.float32 and a.dtype == torch.float32 and not x.requires_grad):
+            # GPU path without the side stream: the two per-frame terms are one kernel each and the whole scalar head of
+            # the objective (masking, sums, normalisation, beta / scale / weights, sign) is ONE launch each way
+            # (csrc/vae_heads.h) instead of ~40 dependent element-wise launches: -33 us per step eager or in a serial graph.
+            # With the LGSSM chain captured on a side stream the same change makes the replayed graph 0.14 ms SLOWER (3.84 vs
+            # 3.70 ms; the thinner graph overlaps worse, not yet understood), so that mode keeps the torch ops.
+            from kvae.vae.fused import BernoulliFrameLogLik, LatentReg, LossHead
+            lpx = BernoulliFrameLogLik.apply(x_mu, x)
+            regf = LatentReg.apply(a, a_mu, a_var)
+            elbo_kf = kf_elbo()
+            mk = None if mask is None else mask.to(device=x.device, dtype=torch.float32).reshape(B, T)
+            loss, elbo_total, elbo_kf_v, vae_elbo, recon, reg = LossHead.apply(
+                lpx, regf, elbo_kf, mk, self.beta, self.config.scale_reconstruction, vae_weight, kf_weight)
+            out = {"loss": loss, "elbo_total": elbo_total, "elbo_kf": elbo_kf_v, "elbo_vae_total": vae_elbo,
+                   "recon": recon, "kl": reg}
         else:
-            elbo_kf = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u,
-                                              A_list, B_list, C_list, mask=mask)
-        elbo_total = vae_weight * vae_elbo + kf_weight * elbo_kf
-        out = {"loss": -elbo_total, "elbo_total": elbo_total, "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
-               "recon": recon, "kl": reg}
+            x_var = torch.tensor(self.config.noise_pixel_var, device=x.device, dtype=x_mu.dtype) \
+                if self.config.out_distr.lower() != "bernoulli" else None
+            vae_elbo, recon, reg = vae_loss(x, x_mu, x_var, a, a_mu, a_var,
+                                            scale_reconstruction=self.config.scale_reconstruction, mask=mask,
+                                            out_distr=self.config.out_distr, beta=self.beta)
+            elbo_kf = kf_elbo()
+            elbo_total = vae_weight * vae_elbo + kf_weight * elbo_kf
+            out = {"loss": -elbo_total, "elbo_total": elbo_total, "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
+                   "recon": recon, "kl": reg}
         if with_metrics:
             active, variances = count_active_units(a_mu)
             out.update(active_units=active, latent_var_0=variances[0].item(), latent_var_1=variances[1].item())

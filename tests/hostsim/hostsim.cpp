@@ -658,3 +658,35 @@ int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const
   return KVAE_OK;
 }
 }
+
+// Scalar head of the objective: plain loops.
+extern "C" {
+int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, const float *elbo_kf, const float *beta,
+                       float scale, float vae_w, float kf_w, float *out, float *coef, int64_t n, void *) {
+  if (!lpx || !regf || !elbo_kf || !beta || !out || !coef) return KVAE_ERR_NULL;
+  if (n < 1) return KVAE_ERR_ARG;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int64_t i = 0; i < n; ++i) {
+    const float mk = mask ? mask[i] : 1.f;
+    s0 += lpx[i] * mk; s1 += regf[i] * mk; s2 += mk;
+  }
+  const float denom = s2 > 1.f ? s2 : 1.f, recon = s0 / denom, reg = s1 / denom;
+  const float vae = scale * recon + beta[0] * reg, tot = vae_w * vae + kf_w * elbo_kf[0];
+  out[0] = -tot; out[1] = tot; out[2] = elbo_kf[0]; out[3] = vae; out[4] = recon; out[5] = reg;
+  coef[0] = -vae_w * scale / denom;
+  coef[1] = -vae_w * beta[0] / denom;
+  return KVAE_OK;
+}
+int kvae_loss_head_bwd(const float *g, const float *coef, const float *mask, float kf_w, float *g_lpx, float *g_regf, float *g_kf,
+                       int64_t n, void *) {
+  if (!g || !coef || !g_lpx || !g_regf || !g_kf) return KVAE_ERR_NULL;
+  if (n < 1) return KVAE_ERR_ARG;
+  for (int64_t i = 0; i < n; ++i) {
+    const float mk = mask ? mask[i] : 1.f;
+    g_lpx[i] = g[0] * coef[0] * mk;
+    g_regf[i] = g[0] * coef[1] * mk;
+  }
+  g_kf[0] = -kf_w * g[0];
+  return KVAE_OK;
+}
+}

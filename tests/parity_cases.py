@@ -322,3 +322,23 @@ def vae_heads_vs_torch(DEV, N):
     assert rel_err(reg.detach().cpu(), ref.detach()) < 2e-5
     for got, want in zip(dev_in, ref_in):
         assert rel_err(got.grad.cpu(), want.grad) < 2e-5
+
+    # scalar head of the objective
+    from kvae.vae.fused import LossHead
+    lpx, rg = torch.randn(B, T, generator=g) * 50, torch.randn(B, T, generator=g)
+    kf = torch.randn((), generator=g)
+    for mk in (None, (torch.rand(B, T, generator=g) < 0.7).float()):
+        ref_in = [t.clone().requires_grad_(True) for t in (lpx, rg, kf)]
+        m = torch.ones(B, T) if mk is None else mk
+        denom = m.sum().clamp(min=1.0)
+        recon, reg = (ref_in[0] * m).sum() / denom, (ref_in[1] * m).sum() / denom
+        vae = 0.3 * recon + 0.7 * reg
+        tot = 1.5 * vae + 0.8 * ref_in[2]
+        (-tot * 2.0).backward()
+        dev_in = [t.clone().to(DEV).requires_grad_(True) for t in (lpx, rg, kf)]
+        out = LossHead.apply(dev_in[0], dev_in[1], dev_in[2], None if mk is None else mk.to(DEV), torch.tensor(0.7).to(DEV), 0.3, 1.5, 0.8)
+        (out[0] * 2.0).backward()
+        for got, want in zip(out, (-tot, tot, kf, vae, recon, reg)):
+            assert rel_err(got.detach().cpu(), want.detach()) < 2e-5
+        for got, want in zip(dev_in, ref_in):
+            assert rel_err(got.grad.cpu(), want.grad) < 2e-5
