@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — sequences/sec of one ELBO training step of the KVAE on synthetic 32x32xT bouncing-ball video.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]           (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c5]
 
-Workload (BASELINE.json configs[1], per GPU): dynamics 'lstm', K=3 modes, z=4, a=2, B=256 sequences of T=50
-frames; weak scaling (configs[2]: 256 sequences per GPU).  A step = zero_grad + forward + loss + backward +
-[one flat RCCL all-reduce] + clip_grad_norm_(10) + Adam (reference kvae/train/train.py:44-58), fp32, inputs
-resident in HBM, random-init weights.  Prints ONE JSON line (rank 0).
+Workloads (per GPU; weak scaling):
+  c2 (default)  BASELINE.json configs[1] / configs[2]: dynamics 'lstm', K=3 modes, z=4, a=2, B=256 sequences of T=50
+  c5            BASELINE.json configs[4] shard: z = u = 16, T = 200, B = 512 per GPU (4096 over 8 GPUs)
+Any of --batch / --seq-len / --z-dim / --dynamics / --modes overrides the preset; `config.workload` always names what ran.
+
+A step = zero_grad + forward (incl. sigmoid(x_logits)) + loss (incl. the active-unit statistics of the reference's
+compute_loss, kept on the device) + backward + [one flat RCCL all-reduce] + clip_grad_norm_(10) + Adam (reference
+kvae/train/train.py:44-58), fp32, inputs resident in HBM, random-init weights.  The CPU baseline leg does the same work.
+
+Ranks: `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank processes itself
+(`python -m torch.distributed.run`, before this process touches a GPU); under torch.distributed.run the flag must
+equal WORLD_SIZE.  Fewer visible devices than ranks is an error (non-zero exit, no JSON line).
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -23,14 +34,96 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("DISABLE_ADDMM_CUDA_LT", "1")        # see kvae/train/train.py: hipBLASLt is not capture-safe
 os.environ.setdefault("TORCH_BLAS_PREFER_HIPBLASLT", "0")
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 _T0 = time.perf_counter()
 MFMA_F32_PEAK_TFS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = vector peak
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
+
+PRESETS = {
+    "c2": dict(batch=256, seq_len=50, z_dim=4, dynamics="lstm", modes=3),
+    "c5": dict(batch=512, seq_len=200, z_dim=16, dynamics="lstm", modes=3),
+}
+BASELINE_NAMES = {
+    (256, 50, 4, "lstm", 3): "BASELINE configs[1] (configs[2] per-GPU shard)",
+    (512, 200, 16, "lstm", 3): "BASELINE configs[4] per-GPU shard (z=u=16, T=200, 512 of 4096 sequences)",
+    (512, 200, 16, "switching", 3): "BASELINE configs[4] per-GPU shard, switching dynamics (per-step Q)",
+}
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(PRESETS), default="c2")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--dynamics", default=None)
+    ap.add_argument("--modes", type=int, default=None)
+    ap.add_argument("--z-dim", type=int, default=None)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the extra >= 2 s steady-state windows")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the LGSSM chain on the main stream")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher/rendezvous rehearsal on the CPU (gloo): no model, no GPU, marks the line dry_run")
+    args = ap.parse_args(argv)
+    for k, v in PRESETS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
+
+
+def workload_name(args, cfg_dims):
+    B, T = args.batch, args.seq_len
+    n, m, p = cfg_dims
+    base = BASELINE_NAMES.get((B, T, n, args.dynamics, args.modes), "custom size (not a BASELINE config)")
+    return (f"{base}: bouncing-ball 32x32, T={T}, batch={B}/GPU, dynamics={args.dynamics} K={args.modes}, z={n}, u={m}, "
+            f"a={p}, full train step (fwd incl. sigmoid(x_logits) + loss incl. active-unit stats + bwd + clip + Adam); "
+            f"both the GPU leg and the cpu_baseline leg do this work")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# rank launcher
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_launch_ranks(args):
+    """--gpus N > 1 without a torch.distributed.run environment: start N ranks as CHILD processes (this process
+    has not touched a GPU: torch.cuda.device_count() does not initialise HIP) and exit with their status."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with "
+                             f"--nproc-per-node {args.gpus} (or drop the launcher and let bench.py spawn the ranks)")
+        return
+    if args.gpus <= 1:
+        return
+    if not args.dry_run_cpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible HIP devices, found {have}; "
+                             "refusing to report a multi-GPU number from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    log(f"spawning {args.gpus} ranks: {' '.join(cmd)}")
+    rc = subprocess.call(cmd)
+    raise SystemExit(rc)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# model / accounting helpers
+# ------------------------------------------------------------------------------------------------------------------
 def algorithmic_bytes(n, m, p, q_per_step):
     """fp32 bytes per (sequence, step), every API-visible tensor touched once."""
     q = 1 if q_per_step else 0
@@ -46,11 +139,11 @@ def lstm_bytes(I, H):
 
 
 def build_model(args, dev):
+    import torch
     from kvae.model.model import KVAE
     from kvae.utils.config import KVAEConfig
     torch.manual_seed(0)   # identical replicas on every rank
-    cfg = KVAEConfig(dynamics_model=args.dynamics, num_modes=args.modes, z_dim=args.z_dim, a_dim=2,
-                     u_dim=args.z_dim if args.z_dim != 4 else 4)   # configs[4] (C5): z = u = 16
+    cfg = KVAEConfig(dynamics_model=args.dynamics, num_modes=args.modes, z_dim=args.z_dim, a_dim=2, u_dim=args.z_dim)
     model = KVAE(cfg)
     with torch.no_grad():  # spread the K modes so the alpha-net / mixing path carries real gradients
         model.kalman_filter.dyn_params.A.add_(0.05 * torch.randn_like(model.kalman_filter.dyn_params.A))
@@ -58,10 +151,6 @@ def build_model(args, dev):
             model.kalman_filter.dyn_params.head_w.bias.zero_()
     model.beta = 1.0
     return cfg, model.to(dev).train()
-
-
-def log(msg):
-    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def usable_cores():
@@ -77,22 +166,25 @@ def usable_cores():
 
 
 def cpu_baseline(args, sd, frames, budget_s=25.0):
-    """The oracle's restatement of the reference training step on the host cores (kind 'port')."""
+    """The oracle's restatement of the reference training step on the host cores (kind 'port'), on a bounded sample:
+    the full batch at c2 size, the first 32 sequences of the shard (full T) at sizes whose full batch takes minutes."""
+    import torch
     from oracle import torch_oracle as O
     threads = usable_cores()
     torch.set_num_threads(threads)
     log(f"cpu_baseline: {threads} threads")
     B, T = frames.shape[:2]
-    x = frames.float()
-    tr = O.OracleTrainer(sd, args.dynamics, lr=7e-3, clip=10.0, beta=1.0)
+    Bs = B if B * T * args.z_dim ** 2 <= 256 * 50 * 16 * 4 else min(B, 32)
+    x = frames[:Bs].float()
+    tr = O.OracleTrainer(sd, args.dynamics, lr=7e-3, clip=10.0, beta=1.0, with_metrics=True)
     g = torch.Generator().manual_seed(5)
 
     def one():
-        eps_a = torch.randn(B * T, 2, generator=g)
-        eps_z = torch.randn(B, T, args.z_dim, generator=g)
+        eps_a = torch.randn(Bs * T, 2, generator=g)
+        eps_z = torch.randn(Bs, T, args.z_dim, generator=g)
         gum = None
         if args.dynamics == "switching":
-            gum = -torch.empty(B, T, args.modes).exponential_(generator=g).log()
+            gum = -torch.empty(Bs, T, args.modes).exponential_(generator=g).log()
         t0 = time.perf_counter()
         tr.step(x, eps_a=eps_a, eps_z=eps_z, gumbel=gum)
         return time.perf_counter() - t0
@@ -100,38 +192,79 @@ def cpu_baseline(args, sd, frames, budget_s=25.0):
     w = one()  # warm-up (thread pools, oneDNN primitives)
     log(f"cpu_baseline: warm-up step {w:.2f}s")
     times = [one()]
-    while sum(times) < budget_s and len(times) < 4:
+    while sum(times) + w < budget_s and len(times) < 4:
         times.append(one())
     log(f"cpu_baseline: steps {[round(t, 2) for t in times]}")
     med = sorted(times)[len(times) // 2]
-    return {"value": round(B / med, 2), "unit": "sequences/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} timed steps (after 1 warm-up) of the same workload, B={B} T={T}, "
-                      f"oracle/torch_oracle.OracleTrainer (torch-CPU restatement of the reference step), median"}
+    what = "the same workload" if Bs == B else f"the first {Bs} of the {B} sequences (full T; sequences are independent)"
+    return {"value": round(Bs / med, 2), "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} timed steps (after 1 warm-up) of {what}, B={Bs} T={T}, "
+                      f"oracle/torch_oracle.OracleTrainer (torch-CPU restatement of the reference step incl. sigmoid and "
+                      f"active-unit stats), median"}
 
 
+def timed_window(trainer, x, steps, world, dev):
+    """`steps` training steps bracketed by barrier + device sync on both sides; MAX over ranks, seconds."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = trainer.step(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def dry_run_cpu(args):
+    """Rehearsal of the launcher + rendezvous path without a GPU (CPU test tier): gloo ranks, one all-reduce."""
+    import torch
+    import torch.distributed as dist
+    from kvae.train.train import init_distributed
+    os.environ["KVAE_DIST_BACKEND"] = "gloo"
+    rank, world, _ = init_distributed(force_cpu=True)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: world size {world} != --gpus {args.gpus}")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else "none",
+                          "allreduce_sum": float(t.item()), "expected_sum": world * (world + 1) / 2,
+                          "config": {"workload": workload_name(args, (args.z_dim, args.z_dim, 2))}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU")
-    ap.add_argument("--seq-len", type=int, default=50)
-    ap.add_argument("--dynamics", default="lstm")
-    ap.add_argument("--modes", type=int, default=3)
-    ap.add_argument("--z-dim", type=int, default=4)
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="keep the LGSSM chain on the main stream")
-    args = ap.parse_args()
+    args = parse_args()
+    maybe_launch_ranks(args)
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
 
+    import torch
+    import torch.distributed as dist
     from kvae import _native
     from kvae.train.synthetic import bouncing_ball
     from kvae.train.train import Trainer, init_distributed
     rank, world, dev = init_distributed()
     if dev.type != "cuda":
         raise SystemExit("bench.py needs a HIP device (the LGSSM path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: world size {world} != --gpus {args.gpus}")
     _native.hip_lib()
-    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)}; building model")
+    backend = dist.get_backend() if world > 1 else "none"
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)} (device {dev.index}), backend {backend} "
+        f"[nccl == RCCL on ROCm]; building model")
     cfg, model = build_model(args, dev)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     B, T = args.batch, args.seq_len
@@ -139,7 +272,9 @@ def main():
     x = frames.float().to(dev)
 
     capture = "hipgraph"
-    trainer = Trainer(model, use_graph=not args.no_graph, world_size=world, overlap_lgssm=not args.no_overlap)
+    mk_trainer = lambda graph, w=world, ov=not args.no_overlap: Trainer(
+        model, use_graph=graph, world_size=w, overlap_lgssm=ov, reference_logging=True)
+    trainer = mk_trainer(not args.no_graph)
     try:
         for _ in range(max(args.warmup, 1)):
             out = trainer.step(x)
@@ -150,85 +285,104 @@ def main():
         print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
         capture = "eager"
         cfg, model = build_model(args, dev)
-        trainer = Trainer(model, use_graph=False, world_size=world)
+        trainer = mk_trainer(False)
         for _ in range(max(args.warmup, 1)):
             out = trainer.step(x)
     if args.no_graph:
         capture = "eager"
     log(f"warm-up done ({capture}); timing {args.steps} steps")
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = trainer.step(x)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- the timed region the contract defines: EXACTLY --steps steps --------------------------------------------
+    elapsed, out = timed_window(trainer, x, args.steps, world, dev)
     loss = float(out["loss"])
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
-
     log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} seq/s")
-    # ---- roofline of the LGSSM kernel chain: HIP events around each C-ABI call, eager launches ----
+
+    # ---- steady state: >= 5 further windows, >= 2 s or >= 200 steps in all; median and spread ----------------------
+    steady = None
+    if not args.no_steady:
+        per = max(4, min(200, int(0.4 / max(ms_per_step * 1e-3, 1e-6)) + 1))   # ~0.4 s per window
+        wins, total_steps, total_s = [], 0, 0.0
+        while len(wins) < 5 or (total_s < 2.0 and total_steps < 200):
+            el, _ = timed_window(trainer, x, per, world, dev)
+            wins.append(1e3 * el / per)
+            total_steps += per
+            total_s += el
+            if len(wins) >= 40:
+                break
+        sw = sorted(wins)
+        med = sw[len(sw) // 2]
+        steady = {"windows": len(wins), "steps_per_window": per, "total_steps": total_steps, "total_s": round(total_s, 3),
+                  "ms_per_step_median": round(med, 4), "ms_per_step_min": round(sw[0], 4), "ms_per_step_max": round(sw[-1], 4),
+                  "value_median": round(world * B / (med * 1e-3), 2)}
+        log(f"steady state: median {med:.3f} ms/step over {len(wins)} windows of {per} steps "
+            f"(min {sw[0]:.3f}, max {sw[-1]:.3f})")
+
+    # ---- roofline of the LGSSM kernel chain: HIP events around each C-ABI call, eager launches --------------------
     roofline, chain = None, {}
     if rank == 0:
-        eager = Trainer(model, use_graph=False, world_size=1)
+        eager = Trainer(model, use_graph=False, world_size=1, reference_logging=True)
         for _ in range(3):
             eager.step(x)
+        n_prof = 10 if B * T <= 20000 else 4
         _native.profile_start()
-        for _ in range(10):
+        for _ in range(n_prof):
             eager.step(x)
         times = _native.profile_stop()
-        per_unit = algorithmic_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, args.dynamics == "switching")
+        q_per_step = args.dynamics == "switching"
+        per_unit = algorithmic_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, q_per_step)
         per_unit.update(lstm_bytes(cfg.a_dim, cfg.dynamics_hidden_dim))
         K = args.modes
         per_unit.update({"regime_fwd": 4 * (K * K + 2 * K + 2), "regime_bwd": 4 * (2 * K * K + 3 * K + 2)})
         for name, ms in times.items():
-            avg = sum(ms) / len(ms)
-            if name not in per_unit:   # VAE convolution calls (timed for the step-dominant entry below)
-                chain[name] = {"avg_us": round(1e3 * avg, 2)}
-                continue
-            nbytes = per_unit[name] * B * T
-            chain[name] = {"avg_us": round(1e3 * avg, 2), "algorithmic_bytes": nbytes,
-                           "GBps": round(nbytes / (avg * 1e-3) / 1e9, 2)}
-        traffic = {}
-        try:   # HBM bytes per launch from the PMC passes committed under profiles/ (same config only)
-            if (B, T, cfg.z_dim, args.dynamics, args.modes) == (256, 50, 4, "lstm", 3):
-                traffic = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+            # a call may be issued as several chunked launches per step (VAE kernels above 16384 frames):
+            # account per STEP (sum of its launches), so that bytes / flop of the whole batch meet the whole time
+            launches = max(1, round(len(ms) / n_prof))
+            per_step_us = 1e3 * sum(ms) / n_prof
+            ent = {"avg_us": round(per_step_us / launches, 2), "launches_per_step": launches,
+                   "per_step_us": round(per_step_us, 2)}
+            if name in per_unit:
+                nbytes = per_unit[name] * B * T
+                ent.update(algorithmic_bytes=nbytes, GBps=round(nbytes / (per_step_us * 1e-6) / 1e9, 2))
+            chain[name] = ent
+        traffic, traffic_src = {}, None
+        try:   # HBM bytes per launch from the PMC passes committed under profiles/ (matching config only)
+            tj = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+            key = f"B{B}_T{T}_n{cfg.z_dim}_{args.dynamics}_K{args.modes}"
+            if key in tj:
+                traffic = tj[key]
+                traffic_src = f"profiles/pmc_traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({tj.get('_round', '?')}), not measured in this run"
         except Exception:
             traffic = {}
         lg = {k: v for k, v in chain.items() if k in ("smooth_fwd", "smooth_bwd", "elbo")}
         if lg:
-            dom = max(lg, key=lambda k: lg[k]["avg_us"])
+            dom = max(lg, key=lambda k: lg[k]["per_step_us"])
             ach = chain[dom]["GBps"]
             n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
-            roofline = {"kernel": {"smooth_fwd": "k_smooth_fwd_n4" if n4 else "k_smooth_fwd",
-                                   "smooth_bwd": "k_smooth_bwd_n4" if n4 else "k_smooth_bwd",
-                                   "elbo": "k_elbo_tpp(+probe)" if n4 else "k_elbo(+probe)"}[dom],
+            n16 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (16, 16, 2)
+            kname = {"smooth_fwd": "k_smooth_fwd_n4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
+                     "smooth_bwd": "k_smooth_bwd_n4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
+                     "elbo": "k_elbo_tpp(+probe)" if n4 else "k_elbo(+probe)"}[dom]
+            roofline = {"kernel": kname,
                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom),
-                        "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["avg_us"],
-                        "note": "latency-bound at this size by construction: T-deep dependent recursion, one wavefront per sequence"}
+                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom), "traffic_source": traffic_src,
+                        "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["per_step_us"],
+                        "note": "T-deep dependent recursion, one sequence per wavefront: latency-bound, not byte-bound, "
+                                "whenever B is far below the ~8000 wave slots of the chip"}
             # the kernel that dominates the STEP is outside the LGSSM path: the decoder 32->128 block on the f32 matrix cores
             up = chain.get("dec_up_fwd_s8")
             if up and (cfg.img_size, tuple(cfg.decoder_channels)) == (32, (32, 32, 32)):
                 flop = 2.0 * B * T * 64 * 128 * 288            # MACs x 2: 64 pixels, 128 output channels, 32 x 9 taps
-                tf = flop / (up["avg_us"] * 1e-6) / 1e12
+                tf = flop / (up["per_step_us"] * 1e-6) / 1e12  # all chunk launches of the step together
                 roofline["step_dominant_kernel"] = {
                     "kernel": "k_dec_up_fwd<8> (conv 32->128 3x3 + PixelShuffle + ReLU, exact-f32 MFMA)", "bound": "mfma",
                     "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFS, 4),
-                    "flop_per_launch": flop, "avg_launch_us": up["avg_us"],
+                    "flop_per_step": flop, "launches_per_step": up["launches_per_step"], "per_step_us": up["per_step_us"],
                     "note": "its data-gradient and weight-gradient twins run at the same rate (profiles/)"}
-            tot_us = sum(c["avg_us"] for c in lg.values())
+            tot_us = sum(c["per_step_us"] for c in lg.values())
             tot_b = sum(c["algorithmic_bytes"] for c in lg.values())
-            chain["chain_total"] = {"avg_us": round(tot_us, 2), "algorithmic_bytes": tot_b,
+            chain["chain_total"] = {"per_step_us": round(tot_us, 2), "algorithmic_bytes": tot_b,
                                     "GBps": round(tot_b / (tot_us * 1e-6) / 1e9, 2)}
 
     cpu = None
@@ -241,10 +395,10 @@ def main():
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: bouncing-ball 32x32, T={T}, batch={B}/GPU, dynamics={args.dynamics} "
-                                   f"K={args.modes}, z={cfg.z_dim}, a={cfg.a_dim}, full train step (fwd+loss+bwd+clip+Adam)",
+            "config": {"workload": workload_name(args, (cfg.z_dim, cfg.u_dim, cfg.a_dim)), "preset": args.config,
                        "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}", "capture": capture,
-                       "final_loss": round(loss, 5)},
+                       "dist_backend": backend, "final_loss": round(loss, 5)},
+            "steady_state": steady,
             "roofline": roofline, "lgssm_chain": chain, "cpu_baseline": cpu,
         }
         if cpu:

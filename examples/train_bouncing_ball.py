@@ -4,7 +4,8 @@
   python examples/train_bouncing_ball.py --epochs 3                       # 1 GPU
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_bouncing_ball.py
 
-Mirrors the reference's kvae/train/train.py loop (phases omitted): beta schedule, Adam + ExponentialLR, grad clip 10,
+Mirrors the reference's kvae/train/train.py loop (phases omitted): beta schedule, Adam + ExponentialLR and the tau decay
+(both reach the captured hipGraph through device scalars), grad clip 10,
 reference-compatible checkpoints; data come from an .npz (uint8 (N,T,H,W), the reference's format) written on the fly.
 """
 import argparse
@@ -21,7 +22,7 @@ from kvae.dataloader.pymunk_dataset import DeviceBatches, PymunkNPZDataset  # no
 from kvae.model.model import KVAE  # noqa: E402
 from kvae.train.checkpoint import Checkpointer  # noqa: E402
 from kvae.train.synthetic import bouncing_ball  # noqa: E402
-from kvae.train.train import Trainer, init_distributed, train_one_epoch  # noqa: E402
+from kvae.train.train import Trainer, end_of_epoch_schedules, init_distributed, train_one_epoch  # noqa: E402
 from kvae.utils.config import KVAEConfig  # noqa: E402
 
 
@@ -33,6 +34,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per GPU")
     ap.add_argument("--dynamics", default="lstm")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--config", default=None, help="reference-style YAML (its `kvae:` section becomes the KVAEConfig)")
+    ap.add_argument("--decay-steps", type=int, default=1, help="epochs between LR decays (reference default: 20)")
     args = ap.parse_args()
     rank, world, dev = init_distributed()
     out = Path(args.out or tempfile.mkdtemp(prefix="kvae_run_"))
@@ -46,7 +49,7 @@ def main():
     ds = PymunkNPZDataset.from_npz(npz, seq_len=args.seq_len, state_key=None)
     loader = DeviceBatches(ds, args.batch, dev, shuffle=True, seed=1, rank=rank, world_size=world)
     torch.manual_seed(0)
-    cfg = KVAEConfig(dynamics_model=args.dynamics)
+    cfg = KVAEConfig.from_yaml(args.config) if args.config else KVAEConfig(dynamics_model=args.dynamics)
     model = KVAE(cfg).to(dev)
     trainer = Trainer(model, lr=7e-3, world_size=world, use_graph=dev.type == "cuda")
     sched = torch.optim.lr_scheduler.ExponentialLR(trainer.opt, gamma=0.85)
@@ -56,9 +59,10 @@ def main():
     for epoch in range(1, args.epochs + 1):
         trainer.set_beta(model.scheduler.get_beta(epoch) if cfg.scheduled_beta else 1.0)
         stats = train_one_epoch(trainer, loader, dev)
-        sched.step()
+        lr, tau = end_of_epoch_schedules(trainer, sched, epoch, decay_steps=args.decay_steps)
         if rank == 0:
-            print(f"epoch {epoch}: loss {stats['loss']:.4f} elbo_kf {stats['elbo_kf']:.4f} elbo_vae {stats['elbo_vae_total']:.4f}")
+            print(f"epoch {epoch}: loss {stats['loss']:.4f} elbo_kf {stats['elbo_kf']:.4f} elbo_vae {stats['elbo_vae_total']:.4f}"
+                  f" | next lr {lr:.3e}" + (f" tau {tau:.3f}" if tau is not None else ""))
             ck.save_checkpoints(stats["loss"], stats["loss"], model, trainer.opt, epoch)
     if world > 1:
         torch.distributed.destroy_process_group()

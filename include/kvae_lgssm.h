@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 3
+#define KVAE_ABI_VERSION 4
 
 typedef enum {
   KVAE_OK = 0,
@@ -170,13 +170,17 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
 
 /* Sequential Gumbel-softmax Markov chain over T steps (switch_dyn_param.py:52-79): logits [B,T,K,K] (slice t=0
  * unused), init_logits [B,K], gumbel noise [B,T,K], prior transition P [K,K], temperature tau, hard != 0 for the
- * straight-through one-hot of eval mode.  Outputs y_seq [B,T,K], log_q [B,T], log_p [B,T].  K <= 16. */
+ * straight-through one-hot of eval mode.  Outputs y_seq [B,T,K], log_q [B,T], log_p [B,T].  K <= 16.
+ * tau_dev (may be NULL): DEVICE scalar holding the temperature; when given it is read by the kernel at run time and
+ * `tau` is ignored, so that a launch captured into a hipGraph follows the tau schedule of the reference's epoch loop
+ * (kvae/train/train.py:270-274) without re-capture. */
 int kvae_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, float *y_seq,
-                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, int32_t hard, void *stream);
+                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, const float *tau_dev,
+                    int32_t hard, void *stream);
 /* BPTT of kvae_regime_fwd: upstream g_y [B,T,K], g_log_q [B,T], g_log_p [B,T] -> g_logits [B,T,K,K], g_init [B,K]. */
 int kvae_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
                     const float *y_seq, const float *g_y, const float *g_log_q, const float *g_log_p, float *g_logits,
-                    float *g_init, int32_t B, int32_t T, int32_t K, float tau, void *stream);
+                    float *g_init, int32_t B, int32_t T, int32_t K, float tau, const float *tau_dev, void *stream);
 
 /* ---- bidirectional GRU of the regime posterior ("switching" dynamics) ------------------------- */
 

@@ -167,11 +167,12 @@ extern "C" void kvae_tpp_launch_elbo(const kvae_lgssm_problem *p, const float *m
                                      float *terms, const int32_t *levels, const float *ws, float *g_mus, float *g_Sigs,
                                      const kvae_lgssm_input_grads *g, int have_g, hipStream_t s);
 extern "C" int kvae_tpp_launch_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
-                                          float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau, int hard,
-                                          hipStream_t s);
+                                          float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau,
+                                          const float *tau_dev, int hard, hipStream_t s);
 extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
-                                          float *g_logits, float *g_init, int B, int T, int K, float tau, hipStream_t s);
+                                          float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
+                                          hipStream_t s);
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s);
 extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
@@ -314,7 +315,7 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
 
 int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
 const char *kvae_last_error(void) { return g_err; }
-const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "3"; }
+const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "4"; }
 
 }  // extern "C"
 
@@ -567,40 +568,46 @@ int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHU
 
 __global__ __launch_bounds__(64) void k_regime_fwd(const float *logits, const float *init_logits, const float *gumbel,
                                                    const float *P, float *y_seq, float *log_q, float *log_p, int T, int K,
-                                                   float tau, int hard) {
+                                                   float tau, const float *tau_dev, int hard) {
   __shared__ RegimeLds L;
+  if (tau_dev) tau = *tau_dev;   // device scalar: follows the schedule under hipGraph replay
   regime_fwd_body(logits, init_logits, gumbel, P, y_seq, log_q, log_p, blockIdx.x, T, K, tau, hard, L);
 }
 __global__ __launch_bounds__(64) void k_regime_bwd(const float *logits, const float *init_logits, const float *gumbel,
                                                    const float *P, const float *y_seq, const float *g_y, const float *g_lq,
-                                                   const float *g_lp, float *g_logits, float *g_init, int T, int K, float tau) {
+                                                   const float *g_lp, float *g_logits, float *g_init, int T, int K, float tau,
+                                                   const float *tau_dev) {
   __shared__ RegimeLds L;
+  if (tau_dev) tau = *tau_dev;
   regime_bwd_body(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, blockIdx.x, T, K, tau, L);
 }
 
 extern "C" {
 int kvae_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, float *y_seq,
-                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, int32_t hard, void *stream) {
+                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, const float *tau_dev, int32_t hard,
+                    void *stream) {
   if (!logits || !init_logits || !gumbel || !P || !y_seq || !log_q || !log_p) return KVAE_ERR_NULL;
-  if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || !(tau > 0.f)) return KVAE_ERR_ARG;
+  if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || (!tau_dev && !(tau > 0.f))) return KVAE_ERR_ARG;
   static const int tpp_env = getenv("KVAE_REGIME_TPP") ? atoi(getenv("KVAE_REGIME_TPP")) : 1;   // 0: wave-per-sequence (A/B runs)
-  if (tpp_env && kvae_tpp_launch_regime_fwd(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, K, tau, hard, (hipStream_t)stream))
+  if (tpp_env && kvae_tpp_launch_regime_fwd(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, K, tau, tau_dev, hard,
+                                            (hipStream_t)stream))
     return launch_status("k_regime_fwd_tpp");
-  k_regime_fwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, T, K, tau, hard);
+  k_regime_fwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, T, K, tau,
+                                                              tau_dev, hard);
   return launch_status("k_regime_fwd");
 }
 int kvae_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, const float *y_seq,
                     const float *g_y, const float *g_log_q, const float *g_log_p, float *g_logits, float *g_init, int32_t B,
-                    int32_t T, int32_t K, float tau, void *stream) {
+                    int32_t T, int32_t K, float tau, const float *tau_dev, void *stream) {
   if (!logits || !init_logits || !gumbel || !P || !y_seq || !g_y || !g_log_q || !g_log_p || !g_logits || !g_init)
     return KVAE_ERR_NULL;
-  if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || !(tau > 0.f)) return KVAE_ERR_ARG;
+  if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || (!tau_dev && !(tau > 0.f))) return KVAE_ERR_ARG;
   static const int tpp_env = getenv("KVAE_REGIME_TPP") ? atoi(getenv("KVAE_REGIME_TPP")) : 1;
   if (tpp_env && kvae_tpp_launch_regime_bwd(logits, init_logits, gumbel, P, y_seq, g_y, g_log_q, g_log_p, g_logits, g_init, B, T, K, tau,
-                                            (hipStream_t)stream))
+                                            tau_dev, (hipStream_t)stream))
     return launch_status("k_regime_bwd_tpp");
   k_regime_bwd<<<dim3(B), dim3(64), 0, (hipStream_t)stream>>>(logits, init_logits, gumbel, P, y_seq, g_y, g_log_q, g_log_p,
-                                                             g_logits, g_init, T, K, tau);
+                                                             g_logits, g_init, T, K, tau, tau_dev);
   return launch_status("k_regime_bwd");
 }
 }  // extern "C"

@@ -58,18 +58,21 @@ extern "C" void kvae_tpp_launch_elbo(const kvae_lgssm_problem *p, const float *m
 template <int KC>
 __global__ __launch_bounds__(64) void k_regime_fwd_tpp(const float *logits, const float *init_logits, const float *gumbel,
                                                        const float *P, float *y_seq, float *log_q, float *log_p, int B, int T,
-                                                       float tau, int hard) {
+                                                       float tau, const float *tau_dev, int hard) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
+  if (tau_dev) tau = *tau_dev;
   RegimeLds L;
   regime_fwd_body(logits, init_logits, gumbel, P, y_seq, log_q, log_p, b, T, KC, tau, hard, L);
 }
 template <int KC>
 __global__ __launch_bounds__(64) void k_regime_bwd_tpp(const float *logits, const float *init_logits, const float *gumbel,
                                                        const float *P, const float *y_seq, const float *g_y, const float *g_lq,
-                                                       const float *g_lp, float *g_logits, float *g_init, int B, int T, float tau) {
+                                                       const float *g_lp, float *g_logits, float *g_init, int B, int T, float tau,
+                                                       const float *tau_dev) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
+  if (tau_dev) tau = *tau_dev;
   RegimeLds L;
   regime_bwd_body(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, b, T, KC, tau, L);
 }
@@ -77,11 +80,11 @@ __global__ __launch_bounds__(64) void k_regime_bwd_tpp(const float *logits, cons
 #define KVAE_REGIME_TPP_CASES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 // return 1 if a thread-per-sequence instance exists for K (and was launched), 0 otherwise
 extern "C" int kvae_tpp_launch_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
-                                          float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau, int hard,
-                                          hipStream_t s) {
+                                          float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau,
+                                          const float *tau_dev, int hard, hipStream_t s) {
   const dim3 grid((unsigned)((B + 63) / 64));
   switch (K) {
-#define X(KC) case KC: k_regime_fwd_tpp<KC><<<grid, dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, tau, hard); return 1;
+#define X(KC) case KC: k_regime_fwd_tpp<KC><<<grid, dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, tau, tau_dev, hard); return 1;
     KVAE_REGIME_TPP_CASES(X)
 #undef X
     default: return 0;
@@ -89,10 +92,11 @@ extern "C" int kvae_tpp_launch_regime_fwd(const float *logits, const float *init
 }
 extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
-                                          float *g_logits, float *g_init, int B, int T, int K, float tau, hipStream_t s) {
+                                          float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
+                                          hipStream_t s) {
   const dim3 grid((unsigned)((B + 63) / 64));
   switch (K) {
-#define X(KC) case KC: k_regime_bwd_tpp<KC><<<grid, dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, B, T, tau); return 1;
+#define X(KC) case KC: k_regime_bwd_tpp<KC><<<grid, dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, B, T, tau, tau_dev); return 1;
     KVAE_REGIME_TPP_CASES(X)
 #undef X
     default: return 0;

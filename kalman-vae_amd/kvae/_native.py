@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -91,9 +91,9 @@ class LgssmLib:
         d.kvae_bias_shuffle_act_fwd.restype = C.c_int
         d.kvae_bias_shuffle_act_bwd.argtypes = [vp, vp, vp, vp, C.c_int64] + [C.c_int32] * 5 + [vp]
         d.kvae_bias_shuffle_act_bwd.restype = C.c_int
-        d.kvae_regime_fwd.argtypes = [vp] * 7 + [C.c_int32] * 3 + [C.c_float, C.c_int32, vp]
+        d.kvae_regime_fwd.argtypes = [vp] * 7 + [C.c_int32] * 3 + [C.c_float, vp, C.c_int32, vp]
         d.kvae_regime_fwd.restype = C.c_int
-        d.kvae_regime_bwd.argtypes = [vp] * 10 + [C.c_int32] * 3 + [C.c_float, vp]
+        d.kvae_regime_bwd.argtypes = [vp] * 10 + [C.c_int32] * 3 + [C.c_float, vp, vp]
         d.kvae_regime_bwd.restype = C.c_int
         d.kvae_bigru_fwd.argtypes = [vp] * 7 + [C.c_int32] * 4 + [vp]
         d.kvae_bigru_fwd.restype = C.c_int

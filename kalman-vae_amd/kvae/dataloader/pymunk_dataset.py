@@ -104,9 +104,15 @@ class DeviceBatches:
         self.host = None if self.resident else (data.pin_memory() if on_gpu else data)
         self.copy_stream = torch.cuda.Stream(self.device) if (on_gpu and not self.resident) else None
 
+    def _per_rank(self):
+        """Sequences every rank iterates over: the same number on all ranks (the trailing remainder of the
+        permutation is dropped), so that every rank issues the same number of all-reduces per epoch."""
+        per = len(self.ds) // self.world
+        return (per // self.bs) * self.bs if self.drop_last else per
+
     def __len__(self):
-        n = len(self.ds) // self.world
-        return n // self.bs if self.drop_last else -(-n // self.bs)
+        per = self._per_rank()
+        return per // self.bs if self.drop_last else -(-per // self.bs)
 
     def _upload(self, idx):
         if self.resident:
@@ -132,9 +138,9 @@ class DeviceBatches:
         n = len(self.ds)
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         order = torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)
-        order = order[self.rank::self.world]                           # equal shards (trailing remainder dropped)
-        order = order[: (len(order) // self.bs) * self.bs] if self.drop_last else order
-        chunks = list(order.split(self.bs))
+        per = self._per_rank()
+        order = order[: (n // self.world) * self.world][self.rank::self.world][:per]   # truncate, THEN stride: equal shards
+        chunks = list(order.split(self.bs)) if per > 0 else []
         self.epoch += 1
         nxt = self._upload(chunks[0]) if chunks else None
         for i in range(len(chunks)):

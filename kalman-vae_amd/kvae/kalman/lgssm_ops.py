@@ -193,6 +193,7 @@ class LgssmElbo(torch.autograd.Function):
     """The LGSSM terms of KalmanFilter.elbo (reference kalman_filter.py:347-389), summed over B and T.
     Returns (total, per_term[4]); gradients are produced in the forward launch (unit upstream) and
     scaled by the incoming scalar gradient in backward."""
+    last_chol_levels = None
 
     @staticmethod
     def forward(ctx, mus, Sigs, eps, Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots):
@@ -217,6 +218,7 @@ class LgssmElbo(torch.autograd.Function):
         per_term = terms.sum((0, 1))
         ctx.sink, ctx.g_mus, ctx.g_Sigs, ctx.mus_shape = sink, g_mus, g_Sigs, mus.shape
         ctx.chol_levels = levels
+        LgssmElbo.last_chol_levels = levels   # device int32[2] (Sigma_s, Q_t): level of _safe_cholesky's ladder, 5 = diagonal
         ctx.mark_non_differentiable(per_term)
         return per_term.sum(), per_term
 
@@ -328,15 +330,21 @@ class RegimeChain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, init_logits, gumbel, P, tau, hard):
+        """`tau`: a float (baked into the launch) or a 0-d fp32 tensor on the logits' device, which the kernel reads
+        at run time - the form that follows the reference's tau schedule (train.py:270-274) under hipGraph replay."""
         logits, init_logits, gumbel, P = (_f32c(t) for t in (logits, init_logits, gumbel, P))
         Bsz, T, K, _ = logits.shape
         mk = lambda *s: torch.empty(*s, device=logits.device, dtype=torch.float32)
         y, lq, lp = mk(Bsz, T, K), mk(Bsz, T), mk(Bsz, T)
         lib = N.lib_for(logits)
+        tau_t = tau if isinstance(tau, torch.Tensor) else None
+        if tau_t is not None and (tau_t.device != logits.device or tau_t.dtype != torch.float32 or tau_t.numel() != 1):
+            raise ValueError("RegimeChain: a tensor tau must be one fp32 element on the device of the logits")
+        tau_f = 0.0 if tau_t is not None else float(tau)
         lib.check(N.timed("regime_fwd", logits, lambda: lib.dll.kvae_regime_fwd(
             N.ptr(logits), N.ptr(init_logits), N.ptr(gumbel), N.ptr(P), N.ptr(y), N.ptr(lq), N.ptr(lp), Bsz, T, K,
-            float(tau), int(hard), N.stream_for(logits))), "kvae_regime_fwd")
-        ctx.tau = float(tau)
+            tau_f, N.ptr(tau_t), int(hard), N.stream_for(logits))), "kvae_regime_fwd")
+        ctx.tau, ctx.tau_t = tau_f, tau_t
         ctx.save_for_backward(logits, init_logits, gumbel, P, y)
         return y, lq, lp
 
@@ -350,7 +358,7 @@ class RegimeChain(torch.autograd.Function):
         lib = N.lib_for(logits)
         lib.check(N.timed("regime_bwd", logits, lambda: lib.dll.kvae_regime_bwd(
             N.ptr(logits), N.ptr(init_logits), N.ptr(gumbel), N.ptr(P), N.ptr(y), N.ptr(g_y), N.ptr(g_lq), N.ptr(g_lp),
-            N.ptr(g_logits), N.ptr(g_init), Bsz, T, K, ctx.tau, N.stream_for(logits))), "kvae_regime_bwd")
+            N.ptr(g_logits), N.ptr(g_init), Bsz, T, K, ctx.tau, N.ptr(ctx.tau_t), N.stream_for(logits))), "kvae_regime_bwd")
         return g_logits, g_init, None, None, None, None
 
 

@@ -2,9 +2,11 @@
 regime samples, a sticky Markov prior, and regime-mixed A_t, B_t, Q_t.
 
 Same classes, constructor signatures and state_dict keys as the reference
-(kvae/kalman/switch_dyn_param.py:7-129).  The bi-GRU and its heads run on PyTorch-ROCm; the mixing
-einsums (switch_dyn_param.py:82-84) are the HIP `kvae_mix_fwd/bwd` kernel producing one packed
-A|B|Q step record.  Gumbel noise can be injected (kvae.noise.inject) for parity tests.
+(kvae/kalman/switch_dyn_param.py:7-129).  On a HIP device with the default shapes (hidden 50, input 2) the bi-GRU
+recurrence is the hand-written `kvae_bigru_fwd/bwd` kernel (its weight gradients are three small rocBLAS GEMMs),
+the Gumbel-softmax regime chain is `kvae_regime_fwd/bwd`, and the mixing einsums (switch_dyn_param.py:82-84) are
+`kvae_mix_fwd/bwd` producing one packed A|B|Q step record; the two linear heads stay torch ops.  Other GRU shapes
+take nn.GRU (MIOpen).  Gumbel noise can be injected (kvae.noise.inject) for parity tests.
 """
 import torch
 import torch.nn as nn
@@ -29,7 +31,7 @@ class SwitchingDynamicsParameter(nn.Module):
         self.is_switching_dynamics = True
         self.K = A.size(0)
         self.n, self.m, self.p = A.size(1), B.size(2), C.size(1)
-        self.tau = 0.5
+        self._tau, self._tau_dev = 0.5, None
         if Q is None:
             Q = torch.eye(self.n, device=A.device, dtype=A.dtype).repeat(self.K, 1, 1)
         self.A = nn.Parameter(A.clone())
@@ -43,6 +45,25 @@ class SwitchingDynamicsParameter(nn.Module):
         self.hidden_size = hidden_lstm
         self.state_seq = None
         self._record = self._slots = None
+
+    # The Gumbel-softmax temperature.  The reference's epoch loop assigns `dyn_params.tau = max(tau_min, tau * rate)`
+    # (kvae/train/train.py:270-274); here the value is mirrored into a device scalar that the regime-chain kernels read
+    # at run time, so the assignment also takes effect on a step that was captured into a hipGraph.
+    @property
+    def tau(self):
+        return self._tau
+
+    @tau.setter
+    def tau(self, value):
+        self._tau = float(value)
+        if self._tau_dev is not None:
+            self._tau_dev.fill_(self._tau)
+
+    def tau_scalar(self, dev):
+        """0-d fp32 device tensor holding tau (created once per device; call once OUTSIDE graph capture)."""
+        if self._tau_dev is None or self._tau_dev.device != dev:
+            self._tau_dev = torch.full((), self._tau, device=dev, dtype=torch.float32)
+        return self._tau_dev
 
     def reset_state(self):
         self.state_seq = None
@@ -96,8 +117,8 @@ class SwitchingDynamicsParameter(nn.Module):
             gumbel = gumbel.to(device=dev, dtype=dt)
         if _native.fused_ok(logits) and self.K <= 16:   # one HIP launch (csrc/regime.h) instead of the T-1 step loop
             P = self._prior_matrix(dev, dt)
-            y_seq, self.log_qseq, self.log_pseq = RegimeChain.apply(logits, init_logits, gumbel, P, self.tau,
-                                                                    not is_training)
+            tau = self.tau_scalar(dev) if logits.is_cuda else self.tau
+            y_seq, self.log_qseq, self.log_pseq = RegimeChain.apply(logits, init_logits, gumbel, P, tau, not is_training)
         else:
             y_seq, self.log_qseq, self.log_pseq = self.regime_chain(logits, init_logits, gumbel, hard=not is_training)
         rec, offs, (A_seq, B_seq, Q_seq) = mix_dynamics(y_seq, [self.A, self.B, self.Q])

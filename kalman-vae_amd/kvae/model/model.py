@@ -2,8 +2,9 @@
 
 Same constructor (`KVAE(config)`), sub-module names (encoder, decoder, kalman_filter[.dyn_params]),
 parameter registration order and state_dict keys, same `forward` / `compute_loss` / `impute`
-signatures and output dictionaries.  The conv VAE runs on PyTorch-ROCm; everything between
-`a_samples` and the LGSSM ELBO runs in the HIP kernels behind `self.kalman_filter`.
+signatures and output dictionaries.  For the reference's default shapes every layer of the frame VAE runs on the
+hand-written HIP kernels of csrc/vae_*.h (kvae/vae/fused.py; other shapes: MIOpen + fused epilogues), and everything
+between `a_samples` and the LGSSM ELBO runs in the HIP kernels behind `self.kalman_filter`.
 """
 import torch
 from torch import nn
@@ -16,9 +17,25 @@ from kvae.vae.losses import LinearScheduler, count_active_units, vae_loss
 from kvae.vae.vae import Decoder, Encoder
 
 
+_FAST_PATH_NOTES = {
+    "lgssm_specialised": "(z,u,a) is neither (4,4,2) nor (16,16,2): the LGSSM runs the run-time-dimension kernels",
+    "lstm_registers": "alpha-net shape is not (hidden 50, a_dim 2): the LSTM runs the run-time-shape kernel",
+    "bigru_registers": "regime posterior shape is not (hidden 50, a_dim 2): the bi-GRU runs on nn.GRU (MIOpen), "
+                       "which cannot be captured into a hipGraph",
+    "vae_default_shapes": "frame VAE is not the reference's default (32x32x1, channels [32,32,32], a_dim 2): "
+                          "convolutions run on MIOpen with fused epilogues",
+}
+
+
 class KVAE(nn.Module):
     def __init__(self, config):
         super().__init__()
+        if hasattr(config, "validate"):
+            config.validate()   # dimension limits of the HIP kernels (n, m, p, K <= 16) fail here, not at the first launch
+            slow = [k for k, v in config.fast_path().items() if not v and k in _FAST_PATH_NOTES]
+            if slow:   # shapes outside the hand-specialised kernels still run, on generic kernels / MIOpen: say so once
+                import warnings
+                warnings.warn("KVAE: " + "; ".join(_FAST_PATH_NOTES[k] for k in slow), stacklevel=2)
         self.config = config
         self.encoder = Encoder(config)
         self.decoder = Decoder(config)
@@ -105,8 +122,9 @@ class KVAE(nn.Module):
         }
 
     def compute_loss(self, x, outputs, kf_weight=1.0, vae_weight=1.0, mask=None, with_metrics=True):
-        """`with_metrics=False` (addition over the reference) skips the three host syncs of the
-        active-unit statistics so that the step can be captured into a hipGraph."""
+        """`with_metrics` (addition over the reference): True = the reference's behaviour (active-unit count and the
+        two latent variances as Python numbers: three host syncs); "device" = the same statistics as device tensors
+        (`active_units`, `latent_variances`), no sync, capturable into a hipGraph; False = skip them."""
         B, T = x.shape[:2]
         a, a_mu, a_var = outputs["a_samples"], outputs["a_mu"], outputs["a_var"]
         A_list, B_list, C_list = outputs["ABC"]
@@ -156,7 +174,10 @@ class KVAE(nn.Module):
             elbo_total = vae_weight * vae_elbo + kf_weight * elbo_kf
             out = {"loss": -elbo_total, "elbo_total": elbo_total, "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
                    "recon": recon, "kl": reg}
-        if with_metrics:
+        if with_metrics == "device":
+            variances = a_mu.detach().reshape(-1, a_mu.shape[-1]).var(dim=0)
+            out.update(active_units=(variances > 1e-2).sum(), latent_variances=variances)
+        elif with_metrics:
             active, variances = count_active_units(a_mu)
             out.update(active_units=active, latent_var_0=variances[0].item(), latent_var_1=variances[1].item())
         return out

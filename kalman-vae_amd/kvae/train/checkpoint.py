@@ -15,7 +15,11 @@ class Checkpointer:
 
     @staticmethod
     def payload(model, optimizer, epoch, train_loss, val_loss):
-        return {"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict(),
+        opt_state = optimizer.state_dict()
+        for g in opt_state["param_groups"]:   # the Trainer keeps lr in a device scalar; the reference's files hold a float
+            if isinstance(g.get("lr"), torch.Tensor):
+                g["lr"] = float(g["lr"])
+        return {"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": opt_state,
                 "train_loss": train_loss, "val_loss": val_loss}
 
     def save_checkpoint(self, path, model, optimizer, epoch, train_loss, val_loss):
@@ -36,5 +40,10 @@ def load_checkpoint(path, model, optimizer=None, map_location="cpu"):
     payload = torch.load(path, map_location=map_location, weights_only=True)
     model.load_state_dict(payload["model_state"], strict=True)
     if optimizer is not None and "optimizer_state" in payload:
+        lr_t = [g["lr"] for g in optimizer.param_groups]
         optimizer.load_state_dict(payload["optimizer_state"])
+        for g, t in zip(optimizer.param_groups, lr_t):   # keep the device scalar a captured step reads; refill it
+            if isinstance(t, torch.Tensor):
+                t.fill_(float(g["lr"]))
+                g["lr"] = t
     return {k: v for k, v in payload.items() if k not in ("model_state", "optimizer_state")}

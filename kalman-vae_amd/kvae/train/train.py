@@ -5,13 +5,18 @@ Adam.step) restated for one process per GPU.
   * gradients of all parameters live in ONE flat fp32 buffer (each p.grad is a view), so gradient
     clipping is two kernels and data-parallel training needs exactly ONE RCCL all-reduce per step
     (~0.45 MB, latency-bound on xGMI: a single bucket, no overlap machinery);
-  * the whole step (convs on MIOpen, LSTM, the HIP LGSSM chain, loss, backward, clip, fused Adam) is
-    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; with >1 rank the graph is cut
-    around the all-reduce;
+  * the whole step (the hand-written VAE kernels of csrc/vae_*.h for the reference's default shapes - MIOpen for
+    other shapes -, the HIP LSTM / bi-GRU, the HIP LGSSM chain, loss, backward, clip, fused Adam) is captured into a
+    hipGraph (torch.cuda.CUDAGraph) and replayed; with >1 rank the graph is cut around the all-reduce;
   * no host synchronisation inside a step: losses stay on the device until the caller reads them
-    (the reference forces six device->host syncs per step).
-Equal shards + mask == 1 make the mean of per-rank gradients the global-batch gradient (the ELBO is
-normalised by the local frame count, kalman_filter.py:392 / losses.py:82).
+    (the reference forces six device->host syncs per step);
+  * everything a schedule moves between steps lives in a DEVICE scalar the captured kernels read: beta of the KL
+    term, the learning rate (Adam is built with a tensor lr, so torch's LRScheduler updates it in place) and the
+    Gumbel-softmax temperature tau (switch_dyn_param.py: the `tau` property).
+Data parallelism: the ELBO is normalised by the LOCAL count of observed frames (kalman_filter.py:392 /
+losses.py:82), so the global-batch gradient is sum_r(count_r * grad_r) / sum_r(count_r): each rank scales its flat
+gradient by its own count, the count rides in one extra slot of the same buffer, and ONE sum-all-reduce carries both
+(SURVEY.md section 5).  With mask == 1 and equal shards this is the plain mean.
 """
 import os
 
@@ -27,20 +32,31 @@ import torch.distributed as dist
 
 class Trainer:
     def __init__(self, model, lr=7e-3, weight_decay=0.0, grad_clip_norm=10.0, kf_weight=1.0, vae_weight=1.0,
-                 use_graph=True, world_size=1, overlap_lgssm=True):
+                 use_graph=True, world_size=1, overlap_lgssm=True, reference_logging=False):
+        """reference_logging: also compute what the reference's step computes for logging only - sigmoid(x_logits)
+        (model.py:165-168 there) and the active-unit statistics (model.py:229) - as device tensors in `self.out`."""
         self.model, self.clip = model, grad_clip_norm
         self.kf_weight, self.vae_weight = kf_weight, vae_weight
         self.world = world_size
+        self.reference_logging = bool(reference_logging)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=torch.float32)
+        n_par = sum(p.numel() for p in self.params)
+        self._flat = torch.zeros(n_par + 1, device=dev, dtype=torch.float32)   # + 1: the local observed-frame count
+        self.flat_grad, self._count = self._flat[:n_par], self._flat[n_par:]
         off, self.grad_views = 0, []
         for p in self.params:
             self.grad_views.append(self.flat_grad[off:off + p.numel()].view_as(p))
             p.grad = self.grad_views[-1]
             off += p.numel()
         on_gpu = dev.type == "cuda"
-        self.opt = torch.optim.Adam(self.params, lr=lr, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
+        # a TENSOR learning rate: the fused capturable Adam kernel reads it from memory, and torch's LRScheduler
+        # updates it with fill_() - the decay of train.py:268-269 then reaches a captured step (a float would be baked in)
+        self.lr_t = torch.tensor(float(lr), device=dev, dtype=torch.float32) if on_gpu else float(lr)
+        self.opt = torch.optim.Adam(self.params, lr=self.lr_t, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
+        dyn = model.kalman_filter.dyn_params
+        if on_gpu and hasattr(dyn, "tau_scalar"):
+            dyn.tau_scalar(dev)   # create the device scalar of tau outside any capture
         # beta of the KL term lives in a device scalar so that the schedule can move without re-capturing the graph
         self.beta_t = torch.tensor(float(model.beta), device=dev, dtype=torch.float32)
         model.beta = self.beta_t
@@ -51,20 +67,30 @@ class Trainer:
             # gradients of the LGSSM parameters are produced on the side stream by design
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.graph_fb = self.graph_opt = None
-        self.static_x = None
+        self.static_x = self.static_mask = None
         self.out = {}
 
     # -- the three segments of a step ---------------------------------------------------------------
-    def _forward_backward(self, x):
+    def _forward_backward(self, x, mask=None):
+        """mask None == all frames observed (the reference passes a mask of ones, train.py:41)."""
         for p in self.params:   # autograd then hands over each gradient tensor as is (no per-parameter add kernel)
             p.grad = None
         self.model.kalman_filter.dyn_params.reset_state()
-        outputs = self.model(x, mask=None, with_recon=False)   # all frames observed == mask of ones (train.py:41)
-        losses = self.model.compute_loss(x, outputs, kf_weight=self.kf_weight, vae_weight=self.vae_weight, mask=None,
-                                         with_metrics=False)
+        outputs = self.model(x, mask=mask, with_recon=self.reference_logging)
+        losses = self.model.compute_loss(x, outputs, kf_weight=self.kf_weight, vae_weight=self.vae_weight, mask=mask,
+                                         with_metrics="device" if self.reference_logging else False)
         losses["loss"].backward()
         self._gather_grads()
         self.out = {k: losses[k].detach() for k in ("loss", "elbo_kf", "elbo_vae_total")}
+        if self.reference_logging:
+            self.out.update(x_recon=outputs["x_recon"], active_units=losses["active_units"],
+                            latent_variances=losses["latent_variances"])
+        if self.world > 1:   # weight of this rank's gradient in the global-batch gradient (module docstring)
+            if mask is None:
+                self._count.fill_(float(x.shape[0] * x.shape[1]))
+            else:
+                self._count.copy_(mask.sum().reshape(1))
+            self.flat_grad.mul_(self._count.clamp(min=1.0))
 
     def _gather_grads(self):
         """All gradients into the flat buffer with ONE multi-tensor copy; p.grad becomes the flat view again."""
@@ -78,10 +104,14 @@ class Trainer:
 
     def _allreduce(self):
         if self.world > 1:
-            dist.all_reduce(self.flat_grad)
-            self.flat_grad.div_(self.world)
+            dist.all_reduce(self._flat)   # sum of count-weighted gradients and, in the last slot, of the counts
 
     def _clip_and_update(self):
+        if self.world > 1:
+            self.flat_grad.div_(self._count.clamp(min=1.0))
+        self._clip_and_update_local()
+
+    def _clip_and_update_local(self):
         if self.clip and self.clip > 0:   # torch.nn.utils.clip_grad_norm_ on the flat view of all grads
             total = torch.linalg.vector_norm(self.flat_grad)
             self.flat_grad.mul_(torch.clamp(self.clip / (total + 1e-6), max=1.0))
@@ -93,33 +123,49 @@ class Trainer:
         self.beta_t.fill_(float(value))
 
     # -- public ---------------------------------------------------------------------------------------
-    def step(self, x):
-        """One optimisation step on batch x [B,T,C,H,W] (already on the device). Returns device scalars."""
+    def set_lr(self, value: float):
+        """Learning rate of every parameter group (the device scalar the captured Adam kernel reads)."""
+        for g in self.opt.param_groups:
+            if isinstance(g["lr"], torch.Tensor):
+                g["lr"].fill_(float(value))
+            else:
+                g["lr"] = float(value)
+
+    def set_tau(self, value: float):
+        """Gumbel-softmax temperature of the switching dynamics (reference train.py:270-274)."""
+        self.model.kalman_filter.dyn_params.tau = float(value)
+
+    def step(self, x, mask=None):
+        """One optimisation step on batch x [B,T,C,H,W] (already on the device); mask [B,T] (1 = observed) or None
+        for all frames observed.  Returns device scalars."""
         if not self.use_graph:
-            self._forward_backward(x)
+            self._forward_backward(x, mask)
             self._allreduce()
             self._clip_and_update()
             return self.out
-        if self.graph_fb is None:
-            self._capture(x)
+        if self.graph_fb is None or (mask is None) != (self.static_mask is None):
+            self._capture(x, mask)
         self.static_x.copy_(x, non_blocking=True)
+        if mask is not None:
+            self.static_mask.copy_(mask, non_blocking=True)
         self.graph_fb.replay()
         if self.world > 1:
             self._allreduce()
             self.graph_opt.replay()
         return self.out
 
-    def _capture(self, x):
+    def _capture(self, x, mask=None):
         try:
             torch.backends.cuda.preferred_blas_library("cublas")   # == rocBLAS on ROCm (see module header)
         except Exception:
             pass
         self.static_x = x.clone()
+        self.static_mask = None if mask is None else mask.to(device=x.device, dtype=torch.float32).clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up outside capture (MIOpen find, allocator, Adam state)
             for _ in range(3):
-                self._forward_backward(self.static_x)
+                self._forward_backward(self.static_x, self.static_mask)
                 self._allreduce()
                 self._clip_and_update()
         torch.cuda.current_stream().wait_stream(side)
@@ -127,22 +173,22 @@ class Trainer:
         self.graph_fb = torch.cuda.CUDAGraph()
         if self.world == 1:
             with torch.cuda.graph(self.graph_fb):
-                self._forward_backward(self.static_x)
+                self._forward_backward(self.static_x, self.static_mask)
                 self._clip_and_update()
         else:
             with torch.cuda.graph(self.graph_fb):
-                self._forward_backward(self.static_x)
+                self._forward_backward(self.static_x, self.static_mask)
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
                 self._clip_and_update()
 
 
-def init_distributed():
+def init_distributed(force_cpu=False):
     """One process per GPU; RCCL ('nccl' on ROCm) over xGMI. Returns (rank, world, device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available():
+    if not force_cpu and torch.cuda.is_available():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     else:
@@ -170,3 +216,23 @@ def train_one_epoch(trainer, loader, device, epoch=None):
         n += 1
     sums = (sums / max(n, 1)).tolist() if sums is not None else [0.0, 0.0, 0.0]
     return {"loss": sums[0], "elbo_kf": sums[1], "elbo_vae_total": sums[2]}
+
+
+def end_of_epoch_schedules(trainer, scheduler, epoch, decay_steps=20, tau_decay_start_epoch=1):
+    """What the reference's main loop does after train_one_epoch (train.py:268-274 there): every `decay_steps` epochs
+    one step of the LR scheduler, and for switching dynamics the Gumbel-softmax temperature
+    tau <- max(tau_min, tau * tau_decay_rate) every `tau_decay_steps` epochs from `tau_decay_start_epoch` on.
+    Both land in device scalars (the tensor lr of Adam, the tau scalar of the dynamics), so a step that has
+    already been captured into a hipGraph follows them.  Returns (lr, tau) as floats for logging."""
+    model = trainer.model
+    cfg = model.config
+    if scheduler is not None and epoch % decay_steps == 0:
+        scheduler.step()
+    dyn = model.kalman_filter.dyn_params
+    tau = None
+    if cfg.dynamics_model.lower() == "switching":
+        if epoch % cfg.tau_decay_steps == 0 and epoch >= tau_decay_start_epoch \
+                and (epoch - tau_decay_start_epoch) % cfg.tau_decay_steps == 0:
+            dyn.tau = max(cfg.tau_min, dyn.tau * cfg.tau_decay_rate)
+        tau = dyn.tau
+    return float(trainer.opt.param_groups[0]["lr"]), tau

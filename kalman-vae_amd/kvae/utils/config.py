@@ -108,12 +108,14 @@ class KVAEConfig:
     def fast_path(self) -> dict:
         """Which hand-specialised kernels this configuration hits (everything else runs the generic instantiations)."""
         n, m, p = self.lgssm_dims()
-        return {
-            "lgssm_n4_fused": (n, m, p) == (4, 4, 2),
-            "lgssm_static_16": (n, m, p) == (16, 16, 2),
-            "lstm_registers": self.dynamics_model.lower() == "lstm" and (self.dynamics_hidden_dim, p) == (50, 2),
-            "bigru_registers": self.dynamics_model.lower() == "switching" and (self.dynamics_hidden_dim, p) == (50, 2),
-            "regime_chain": self.dynamics_model.lower() == "switching" and self.num_modes <= 16,
+        lstm, sw = self.dynamics_model.lower() == "lstm", self.dynamics_model.lower() == "switching"
+        rnn_ok = (self.dynamics_hidden_dim, p) == (50, 2) or self.num_modes == 1
+        return {   # True = on the specialised kernel (or not applicable to this configuration)
+            "lgssm_specialised": (n, m, p) in ((4, 4, 2), (16, 16, 2)),
+            "lstm_registers": (not lstm) or rnn_ok,
+            "bigru_registers": (not sw) or rnn_ok,
+            "vae_default_shapes": (self.img_size, self.img_channels, self.a_dim, list(self.encoder_channels),
+                                   list(self.decoder_channels)) == (32, 1, 2, [32, 32, 32], [32, 32, 32]),
         }
 
     def describe(self) -> str:

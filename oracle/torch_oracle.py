@@ -341,8 +341,9 @@ def vae_elbo_bernoulli(x, x_logits, a, a_mu, a_var, mask, scale_reconstruction, 
 
 def kvae_forward(sd, x, mask, *, kind, eps_a, eps_z=None, gumbel=None, u=None, training=True, tau=1.0,
                  noise_emission=0.03, sticky_p_stay=0.8, beta=1.0, scale_reconstruction=0.3,
-                 kf_weight=1.0, vae_weight=1.0, with_loss=True):
-    """KVAE.forward + compute_loss (model.py:134-241), bernoulli output, injected noise."""
+                 kf_weight=1.0, vae_weight=1.0, with_loss=True, with_metrics=False):
+    """KVAE.forward + compute_loss (model.py:134-241), bernoulli output, injected noise.
+    with_metrics: also the logging-only statistics of compute_loss (count_active_units, losses.py:137-149; model.py:229)."""
     Bsz, T = x.shape[:2]
     a_mu, a_var = encoder(sd, x.reshape(-1, *x.shape[2:]), noise_emission)
     a = a_mu + eps_a * torch.sqrt(a_var + 1e-6)                                        # model.py:81-84
@@ -368,6 +369,9 @@ def kvae_forward(sd, x, mask, *, kind, eps_a, eps_z=None, gumbel=None, u=None, t
                              out.get("log_qseq"), out.get("log_pseq"))
         elbo_total = vae_weight * vae_elbo + kf_weight * elbo_kf                       # :225
         out.update(loss=-elbo_total, elbo_kf=elbo_kf, elbo_vae_total=vae_elbo, recon=recon, kl=reg)
+        if with_metrics:
+            variances = a_mu.detach().reshape(-1, a_mu.shape[-1]).var(dim=0)
+            out.update(active_units=int((variances > 1e-2).sum().item()), latent_variances=variances)
     return out
 
 

@@ -81,3 +81,8 @@ def stability_state_dict(kind, K, n=4, p=2):
     sd["kalman_filter.mu0"] = torch.zeros(n)
     sd["kalman_filter.Sigma0"] = 20.0 * torch.eye(n)
     return sd
+
+
+# round-2 fixtures (tests/golden/make_goldens_r2.py): (name, expected [level Sigma_s, level Q_t]); 5 = diagonal fallback
+JITTER_CASES = [("jitter_q_level1", [0, 1]), ("jitter_sigma_level2", [2, 0]), ("jitter_diag_fallback", [0, 5])]
+JITTER_GRADS = ["mu_s", "Sig_s", "a", "A_list", "B_list", "C_list", "Q_list"]

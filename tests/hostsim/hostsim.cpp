@@ -248,8 +248,10 @@ int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in,
 #include "../../kalman-vae_amd/csrc/regime.h"
 extern "C" {
 int kvae_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, float *y_seq,
-                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, int32_t hard, void *) {
+                    float *log_q, float *log_p, int32_t B, int32_t T, int32_t K, float tau, const float *tau_dev, int32_t hard,
+                    void *) {
   if (!logits || !init_logits || !gumbel || !P || !y_seq || !log_q || !log_p) return KVAE_ERR_NULL;
+  if (tau_dev) tau = *tau_dev;
   if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || !(tau > 0.f)) return KVAE_ERR_ARG;
   auto L = std::make_unique<RegimeLds>();
   for (int b = 0; b < B; ++b) {
@@ -260,9 +262,10 @@ int kvae_regime_fwd(const float *logits, const float *init_logits, const float *
 }
 int kvae_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P, const float *y_seq,
                     const float *g_y, const float *g_log_q, const float *g_log_p, float *g_logits, float *g_init, int32_t B,
-                    int32_t T, int32_t K, float tau, void *) {
+                    int32_t T, int32_t K, float tau, const float *tau_dev, void *) {
   if (!logits || !init_logits || !gumbel || !P || !y_seq || !g_y || !g_log_q || !g_log_p || !g_logits || !g_init)
     return KVAE_ERR_NULL;
+  if (tau_dev) tau = *tau_dev;
   if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || !(tau > 0.f)) return KVAE_ERR_ARG;
   auto L = std::make_unique<RegimeLds>();
   for (int b = 0; b < B; ++b) {

@@ -1,7 +1,9 @@
 """N>1 path on CPU: two gloo ranks, each a shard of the minibatch, ONE flat all-reduce per step
 (kvae/train/train.py).  Checks (a) replicas stay bit-identical, (b) the 2-rank step equals the single-
-process step on the concatenated global batch (equal shards, mask == 1 => mean of shard gradients is the
-global-batch gradient).  Kernels run in the test-only host simulation."""
+process step on the concatenated global batch - with mask == 1 (mean of shard gradients) AND with a different
+number of observed frames per rank (the ELBO is normalised by the local count, kalman_filter.py:392 / losses.py:82,
+so the ranks' gradients are weighted by their counts inside the same all-reduce).  Kernels run in the test-only
+host simulation."""
 import os
 import socket
 import sys
@@ -46,39 +48,51 @@ def _data(world):
         -torch.empty(B, T, 3).exponential_(generator=g).log()
 
 
-def _step(model, world, rank, x, eps_a, eps_z, gum):
+def _mask(world, unequal):
+    """None (all observed) or a [B,T] mask whose ranks observe different numbers of frames (rank 0: 5 of 8 per
+    sequence, rank 1: 7 of 8, plus one fully hidden sequence on rank 0)."""
+    if not unequal:
+        return None
+    m = torch.ones(B_LOCAL * world, T)
+    m[:B_LOCAL, 2:5] = 0.0
+    m[B_LOCAL:, 6] = 0.0
+    m[1, :] = 0.0
+    return m
+
+
+def _step(model, world, rank, x, eps_a, eps_z, gum, mask=None):
     from kvae import noise
     from kvae.train.train import Trainer
     tr = Trainer(model, use_graph=False, world_size=world)
     sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL) if world > 1 else slice(None)
     ea = eps_a.view(-1, T, 2)[sl].reshape(-1, 2)
     with noise.inject(eps_a=ea, eps_z=eps_z[sl], gumbel=gum[sl]):
-        out = tr.step(x[sl])
+        out = tr.step(x[sl], None if mask is None else mask[sl])
     return tr, out
 
 
-def _worker(rank, world, port, kind, q):
+def _worker(rank, world, port, kind, q, unequal=False):
     torch.set_num_threads(1)
     _setup()
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tr, out = _step(_model(kind), world, rank, *_data(world))
+    tr, out = _step(_model(kind), world, rank, *_data(world), mask=_mask(world, unequal))
     flat = torch.cat([p.detach().flatten() for p in tr.model.parameters()])
     q.put((rank, flat.numpy().copy(), tr.flat_grad.numpy().copy(), float(out["loss"])))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["lstm", "switching"])
-def test_two_rank_step_matches_global_batch(kind):
+@pytest.mark.parametrize("kind,unequal", [("lstm", False), ("switching", False), ("switching", True), ("lstm", True)])
+def test_two_rank_step_matches_global_batch(kind, unequal):
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q, unequal)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
@@ -90,9 +104,15 @@ def test_two_rank_step_matches_global_batch(kind):
     assert torch.equal(g0, g1), "all-reduced gradients differ between ranks"
     # single process, global batch
     _setup()
-    tr, out = _step(_model(kind), 1, 0, *_data(world))
+    tr, out = _step(_model(kind), 1, 0, *_data(world), mask=_mask(world, unequal))
     gref = tr.flat_grad
     assert float((g0 - gref).abs().max() / gref.abs().max()) < 2e-4
     pref = torch.cat([p.detach().flatten() for p in tr.model.parameters()])
     assert float((p0 - pref).abs().max()) < 2e-3   # one Adam step of lr 7e-3: sign-level agreement
-    assert abs(0.5 * (l0 + l1) - float(out["loss"])) < 1e-4 * abs(float(out["loss"]))
+    if unequal:   # the global loss is the count-weighted mean of the rank losses
+        m = _mask(world, True)
+        c0, c1 = float(m[:B_LOCAL].sum()), float(m[B_LOCAL:].sum())
+        assert c0 != c1
+        assert abs((c0 * l0 + c1 * l1) / (c0 + c1) - float(out["loss"])) < 1e-4 * abs(float(out["loss"]))
+    else:
+        assert abs(0.5 * (l0 + l1) - float(out["loss"])) < 1e-4 * abs(float(out["loss"]))

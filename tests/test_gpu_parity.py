@@ -7,7 +7,7 @@ import ctypes as C
 import pytest
 import torch
 
-from golden_util import LATENT_CASES, SMOOTH_KEYS, load, rel_err, stability_state_dict, sub
+from golden_util import JITTER_CASES, LATENT_CASES, SMOOTH_KEYS, load, rel_err, stability_state_dict, sub
 import parity_cases
 from parity_cases import _random_problem
 from test_hostsim_ops import check_latent, make_filter, run_latent
@@ -118,6 +118,12 @@ def test_linearity_full_size():
 
 def test_safe_cholesky_levels():
     parity_cases.safe_cholesky_levels(DEV)
+
+
+@pytest.mark.parametrize("name,levels", JITTER_CASES)
+def test_jitter_golden_gpu(name, levels):
+    """_safe_cholesky past level 0, pinned to the REFERENCE (fixtures driven through its own elbo)."""
+    parity_cases.jitter_golden(DEV, name, levels)
 
 
 def test_c_abi_direct_and_errors():

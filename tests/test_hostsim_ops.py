@@ -5,7 +5,7 @@ a GPU; the same comparisons run against the real gfx950 library in tests/test_gp
 import pytest
 import torch
 
-from golden_util import LATENT_CASES, SMOOTH_KEYS, load, rel_err, sub
+from golden_util import JITTER_CASES, LATENT_CASES, SMOOTH_KEYS, load, rel_err, sub
 from hostsim.build import build as build_hostsim
 
 torch.set_num_threads(4)
@@ -38,11 +38,15 @@ def make_filter(g, kind, device="cpu"):
 
 
 def run_latent(kf, g, device="cpu"):
+    """Fixtures without gradients run under no_grad, as the reference produced them (eval / imputation): with the
+    lstm alpha-net and hidden frames that is the path with the network INSIDE the filter kernel."""
+    import contextlib
     from kvae import noise
-    a = g["a"].to(device).clone().requires_grad_(True)
+    need_grad = "grad.a" in g
+    a = g["a"].to(device).clone().requires_grad_(need_grad)
     u, mask = g["u"].to(device), g["mask"].to(device)
     kf.dyn_params.reset_state()
-    with noise.inject(eps_z=g["eps_z"], gumbel=g.get("gumbel")):
+    with noise.inject(eps_z=g["eps_z"], gumbel=g.get("gumbel")), (contextlib.nullcontext() if need_grad else torch.no_grad()):
         outs = kf.smooth(a, u, mask=None if bool((mask == 1).all()) else mask)
         elbo = kf.elbo(outs[0], outs[1], a, u, outs[6], outs[7], outs[8], mask=mask)
     return a, outs, elbo
@@ -126,6 +130,12 @@ def test_linearity_hostsim():
 def test_safe_cholesky_levels_hostsim():
     import parity_cases
     parity_cases.safe_cholesky_levels("cpu")
+
+
+@pytest.mark.parametrize("name,levels", JITTER_CASES)
+def test_jitter_golden_hostsim(name, levels):
+    import parity_cases
+    parity_cases.jitter_golden("cpu", name, levels)
 
 
 @pytest.mark.parametrize("B,T,I,H", [(3, 7, 2, 50), (2, 5, 5, 13), (1, 1, 2, 50)])

@@ -3,7 +3,7 @@
 import pytest
 import torch
 
-from golden_util import LATENT_CASES, SMOOTH_KEYS, load, rel_err, stability_state_dict, sub
+from golden_util import JITTER_CASES, JITTER_GRADS, LATENT_CASES, SMOOTH_KEYS, load, rel_err, stability_state_dict, sub
 from oracle import torch_oracle as O
 
 torch.set_num_threads(4)
@@ -142,3 +142,31 @@ def test_c_oracle_rocket():
     terms, _ = c_oracle.elbo_terms(out["mus_smooth"], out["Sigmas_smooth"], g["eps_z"], g["Y"], g["U"], None,
                                    g["A"][0], g["B"][0], g["C"][0], g["Qk"][0], g["R"], g["mu0"], g["Sigma0"])
     assert abs(terms.sum() / g["Y"].shape[0] / g["Y"].shape[1] - float(g["elbo"])) < 2e-5 * abs(float(g["elbo"]))
+
+
+# ---- _safe_cholesky past level 0 (kalman_filter.py:282-302): fixtures driven through the reference's own elbo ----
+@pytest.mark.parametrize("name,levels", JITTER_CASES)
+def test_jitter_ladder_torch_oracle(name, levels):
+    g = load(name)
+    # the reference made (level+1) attempts per matrix family, 5 when it fell through to the diagonal
+    assert int(g["cholesky_attempts"]) == sum(min(l + 1, 5) for l in levels)
+    leaves = {k: g[k].clone().requires_grad_(True) for k in JITTER_GRADS}
+    elbo = O.lgssm_elbo(leaves["mu_s"], leaves["Sig_s"], leaves["a"], g["u"], leaves["A_list"], leaves["B_list"],
+                        leaves["C_list"], leaves["Q_list"], g["R"], g["mu0"], g["Sigma0"], g["mask"], g["eps_z"])
+    assert rel_err(elbo.detach(), g["elbo"]) < 1e-5
+    grads = torch.autograd.grad(-elbo, list(leaves.values()), allow_unused=True)
+    for k, gr in zip(leaves, grads):
+        ref = g["grad." + k]
+        gr = torch.zeros_like(ref) if gr is None else gr
+        assert rel_err(gr, ref) < 2e-4, k
+
+
+@pytest.mark.parametrize("name,levels", JITTER_CASES)
+def test_jitter_ladder_c_oracle(name, levels):
+    from oracle import c_oracle
+    g = load(name)
+    terms, lv = c_oracle.elbo_terms(g["mu_s"], g["Sig_s"], g["eps_z"], g["a"], g["u"], g["mask"], g["A_list"],
+                                    g["B_list"], g["C_list"], g["Q_list"], g["R"], g["mu0"], g["Sigma0"])
+    assert list(lv) == levels
+    elbo = terms.sum() / max(float(g["mask"].sum()), 1.0)
+    assert abs(elbo - float(g["elbo"])) <= 3e-5 * abs(float(g["elbo"])), (elbo, float(g["elbo"]))
