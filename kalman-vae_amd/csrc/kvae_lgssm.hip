@@ -175,6 +175,21 @@ extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init
                                           hipStream_t s);
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s);
+// kvae_lgssm_n16.hip: (n, m, p) = (16, 16, 2) on the f32 matrix cores
+extern "C" void kvae_n16_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
+                                    hipStream_t s);
+
+extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                                    const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s);
+
+// The n = 16 kernels move matrices with 16-byte accesses: every per-step operand must start on a 16-byte boundary.
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool stack16(const kvae_stack &s) { return aligned16(s.ptr) && s.sb % 4 == 0 && s.st % 4 == 0; }
+static bool n16_ok(const kvae_lgssm_problem *p) {
+  static const int env = getenv("KVAE_N16") ? atoi(getenv("KVAE_N16")) : 1;   // 0: generic kernels (A/B runs)
+  return env && p->n == 16 && p->m == 16 && p->p == 2 && stack16(p->A) && stack16(p->Bm) && stack16(p->C) && stack16(p->Q) &&
+         aligned16(p->mu0) && p->mu0_sb % 4 == 0 && aligned16(p->Sigma0) && p->Sigma0_sb % 4 == 0 && aligned16(p->U);
+}
 extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                                      const kvae_lgssm_input_grads *out, float *ws, int with_rts, hipStream_t s);
 
@@ -194,6 +209,11 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
     // rts-only calls need no gains; filter calls use the fused-phase kernel when the caller provides aux
     k_smooth_fwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts);
     return launch_status("k_smooth_fwd_n4");
+  }
+  if (n16_ok(prob) && aligned16(st->mus_filt) && aligned16(st->Sigmas_filt) && aligned16(st->mus_pred) &&
+      aligned16(st->Sigmas_pred) && aligned16(st->mus_smooth) && aligned16(st->Sigmas_smooth) && aligned16(st->aux)) {
+    kvae_n16_launch_fwd(prob, st, do_filter, do_rts, s);
+    return launch_status("k_smooth_fwd_n16");
   }
   if (prob->n > 8) {
     kvae_wide_launch_fwd(prob, st, do_filter, do_rts, s);
@@ -243,6 +263,19 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {
     k_smooth_bwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws, with_rts);
     return launch_status("k_smooth_bwd_n4");
+  }
+  if (with_rts && saved->aux && n16_ok(prob)) {
+    // matrix-core backward (lgssm_n16.h): needs the gains saved by the forward, the upstream gradient of the smoothed
+    // stacks, and the upstream gradients of the filtered / predicted stacks either all present or all absent
+    const int fp = (up->mus_filt != nullptr) + (up->Sigmas_filt != nullptr) + (up->mus_pred != nullptr) + (up->Sigmas_pred != nullptr);
+    const bool al = aligned16(saved->mus_filt) && aligned16(saved->Sigmas_filt) && aligned16(saved->mus_pred) &&
+                    aligned16(saved->Sigmas_pred) && aligned16(saved->mus_smooth) && aligned16(saved->Sigmas_smooth) &&
+                    aligned16(saved->aux) && aligned16(ws) && aligned16(up->Sigmas_smooth) && aligned16(up->Sigmas_filt) &&
+                    aligned16(up->Sigmas_pred) && aligned16(out->gA.ptr) && out->gA.sb % 4 == 0 && out->gA.st % 4 == 0;
+    if (up->mus_smooth && up->Sigmas_smooth && (fp == 0 || fp == 4) && al && out->gU) {
+      kvae_n16_launch_bwd(prob, saved, up, out, ws, fp == 4, s);
+      return launch_status("k_smooth_bwd_n16");
+    }
   }
   if (prob->n > 8 && getenv("KVAE_WIDE_BWD")) {   // measured slower than one wavefront at n = 16 (17.9 vs 15.6 ms at the C5
     kvae_wide_launch_bwd(prob, saved, up, out, ws, with_rts, s);   // shard): the backward is bound by its serial solves; opt-in only

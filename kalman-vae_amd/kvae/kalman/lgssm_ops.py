@@ -145,6 +145,9 @@ class LgssmSmooth(torch.autograd.Function):
         call.lib.check(N.timed("smooth_fwd" if with_rts else "filter_fwd", call.Y,
                                lambda: fn(C.byref(call.prob), C.byref(st), call.stream)), "kvae_lgssm_smooth_fwd")
         ctx.slots, ctx.with_rts = slots, with_rts
+        # outputs nobody differentiates arrive as None in backward (not as materialised zero stacks): the kernels take
+        # NULL for "no upstream gradient" and skip the loads
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss, aux)
         if with_rts:
             return ms, Ss, mf, Sf, mp, Sp

@@ -154,6 +154,28 @@ class Trainer:
             self.graph_opt.replay()
         return self.out
 
+    def _snapshot(self):
+        """Parameters and optimizer state before the capture warm-up (which runs real optimizer steps so that the Adam
+        moments exist at static addresses before capture)."""
+        return ([p.detach().clone() for p in self.params],
+                {id(p): {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                 for p, st in self.opt.state.items()})
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        saved_p, saved_state = snap
+        torch._foreach_copy_(self.params, saved_p)
+        for p, st in self.opt.state.items():
+            old = saved_state.get(id(p))
+            for k, v in st.items():
+                if not isinstance(v, torch.Tensor):
+                    if old is not None:
+                        st[k] = old[k]
+                elif old is not None:
+                    v.copy_(old[k])
+                else:
+                    v.zero_()      # state created by the warm-up: back to a fresh optimizer (step 0, zero moments), in place
+
     def _capture(self, x, mask=None):
         try:
             torch.backends.cuda.preferred_blas_library("cublas")   # == rocBLAS on ROCm (see module header)
@@ -164,10 +186,12 @@ class Trainer:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up outside capture (MIOpen find, allocator, Adam state)
+            snap = self._snapshot()
             for _ in range(3):
                 self._forward_backward(self.static_x, self.static_mask)
                 self._allreduce()
                 self._clip_and_update()
+            self._restore(snap)                # the warm-up steps must not count as training steps
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
