@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 4
+#define KVAE_ABI_VERSION 5
 
 typedef enum {
   KVAE_OK = 0,
@@ -102,11 +102,14 @@ int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
 /* Kalman filter with the LSTM alpha-network stepped INSIDE the kernel (masked sequences: the network input of a
  * hidden step is C_t mu_{t|t-1}, kalman_filter.py:183-185; dyn_param.py:39-63).  prob->A/Bm/C are ignored: the step
  * matrices are mixed from the K mode matrices A[K,n,n], Bm[K,n,m], C[K,p,n] and ALSO written to record [B,T,n*n+n*m+p*n]
- * (A|B|C per step) and alpha [B,T,K].  Forward only.  Limits: H == 50, p == 2, K <= 16 (else KVAE_ERR_DIMS). */
+ * (A|B|C per step) and alpha [B,T,K].  The last four pointers are optional (NULL): the cell's internals kept for
+ * kvae_lgssm_alpha_lstm_bwd - gates [B,T,4H] (post-activation, torch order i,f,g,o), c_seq and h_seq [B,T,H], x_seq [B,T,p]
+ * (the cell inputs y_for_dyn).  Limits: H == 50, p == 2, K <= 16 (else KVAE_ERR_DIMS). */
 int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, const float *w_ih,
                                  const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
                                  const float *head_b, const float *A, const float *Bm, const float *C, int32_t K, int32_t H,
-                                 float *record, float *alpha, void *stream);
+                                 float *record, float *alpha, float *gates, float *c_seq, float *h_seq, float *x_seq,
+                                 void *stream);
 
 /* ---- backward ----------------------------------------------------------------------------- */
 
@@ -117,6 +120,21 @@ int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgss
 int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved,
                           const kvae_lgssm_states *up, const kvae_lgssm_input_grads *out,
                           float *ws, int with_rts, void *stream);
+
+/* Reverse-mode of kvae_lgssm_filter_alpha_lstm (with_rts = 0) or of it followed by kvae_lgssm_rts_fwd (with_rts = 1) in
+ * ONE launch: the adjoints of the filter and of the LSTM cell are interleaved step by step, because on hidden frames the
+ * cell input is C_t mu_{t|t-1} (kalman_filter.py:183-185; dyn_param.py:39-63) - what autograd unrolls into T cell steps and
+ * T filter steps.  prob->A/Bm/C must be the stacks of the forward's `record`; out->gA/gB/gC must point into g_record
+ * [B,T,n*n+n*m+p*n] with the same slot offsets.  Upstream: `up` (six stacks, any NULL), g_record_up / g_alpha_up (NULL = none).
+ * Results: out->gY, gU (+ g_mu0, g_Sigma0), g_record (total gradient of the step records: reduce with kvae_mix_bwd for the
+ * mode matrices), d_pre [B,T,4H] (gate pre-activation gradients: the LSTM weight gradients are GEMMs on it, as for
+ * kvae_lstm_bwd) and g_logit [B,T,K] (head gradients likewise).  ws as for kvae_lgssm_smooth_bwd. */
+int kvae_lgssm_alpha_lstm_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                              const kvae_lgssm_input_grads *out, float *ws, int with_rts, const float *w_ih,
+                              const float *w_hh, const float *head_w, const float *A, const float *Bm, const float *C,
+                              int32_t K, int32_t H, const float *alpha, const float *gates, const float *c_seq,
+                              const float *g_record_up, const float *g_alpha_up, float *g_record, float *d_pre,
+                              float *g_logit, void *stream);
 
 /* ---- ELBO --------------------------------------------------------------------------------- */
 

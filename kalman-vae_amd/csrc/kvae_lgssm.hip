@@ -196,7 +196,14 @@ extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgs
 extern "C" int kvae_wide_launch_filter_alpha_lstm(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, const float *w_ih,
                                                   const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
                                                   const float *head_b, const float *A, const float *Bm, const float *C, int K,
-                                                  int H, float *record, float *alpha, hipStream_t s);
+                                                  int H, float *record, float *alpha, float *gates, float *c_seq, float *h_seq,
+                                                  float *x_seq, hipStream_t s);
+extern "C" int kvae_wide_launch_alpha_lstm_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved,
+                                               const kvae_lgssm_states *up, const kvae_lgssm_input_grads *out, float *ws, int with_rts,
+                                               const float *w_ih, const float *w_hh, const float *head_w, const float *A,
+                                               const float *Bm, const float *C, int K, int H, const float *alpha, const float *gates,
+                                               const float *c_seq, const float *g_record_up, const float *g_alpha_up, float *g_record,
+                                               float *d_pre, float *g_logit, hipStream_t s);
 
 static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int do_filter, int do_rts,
                       void *stream) {
@@ -238,7 +245,8 @@ int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
 int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, const float *w_ih,
                                  const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
                                  const float *head_b, const float *A, const float *Bm, const float *C, int32_t K, int32_t H,
-                                 float *record, float *alpha, void *stream) {
+                                 float *record, float *alpha, float *gates, float *c_seq, float *h_seq, float *x_seq,
+                                 void *stream) {
   if (!prob || !out) return KVAE_ERR_NULL;
   if (prob->B < 1 || prob->T < 1 || prob->n < 1 || prob->m < 1 || prob->n > KVAE_MAX_DIM || prob->m > KVAE_MAX_DIM)
     return KVAE_ERR_DIMS;
@@ -247,8 +255,27 @@ int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgss
       !out->Sigmas_pred)
     return KVAE_ERR_NULL;
   const int rc = kvae_wide_launch_filter_alpha_lstm(prob, out, w_ih, w_hh, b_ih, b_hh, head_w, head_b, A, Bm, C, K, H, record,
-                                                    alpha, (hipStream_t)stream);
+                                                    alpha, gates, c_seq, h_seq, x_seq, (hipStream_t)stream);
   return rc ? rc : launch_status("k_filter_alpha_lstm");
+}
+
+int kvae_lgssm_alpha_lstm_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                              const kvae_lgssm_input_grads *out, float *ws, int with_rts, const float *w_ih,
+                              const float *w_hh, const float *head_w, const float *A, const float *Bm, const float *C,
+                              int32_t K, int32_t H, const float *alpha, const float *gates, const float *c_seq,
+                              const float *g_record_up, const float *g_alpha_up, float *g_record, float *d_pre,
+                              float *g_logit, void *stream) {
+  int rc = check_problem(prob);
+  if (rc) return rc;
+  if (!saved || !up || !out || !ws || !w_ih || !w_hh || !head_w || !A || !Bm || !C || !alpha || !gates || !c_seq || !g_record ||
+      !d_pre || !g_logit)
+    return KVAE_ERR_NULL;
+  if (!saved->mus_filt || !saved->Sigmas_filt || !saved->mus_pred || !saved->Sigmas_pred) return KVAE_ERR_NULL;
+  if (with_rts && (!saved->mus_smooth || !saved->Sigmas_smooth)) return KVAE_ERR_NULL;
+  if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
+  rc = kvae_wide_launch_alpha_lstm_bwd(prob, saved, up, out, ws, with_rts, w_ih, w_hh, head_w, A, Bm, C, K, H, alpha, gates, c_seq,
+                                       g_record_up, g_alpha_up, g_record, d_pre, g_logit, (hipStream_t)stream);
+  return rc ? rc : launch_status("k_alpha_lstm_bwd");
 }
 
 int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
@@ -348,7 +375,7 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
 
 int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
 const char *kvae_last_error(void) { return g_err; }
-const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "4"; }
+const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "5"; }
 
 }  // extern "C"
 

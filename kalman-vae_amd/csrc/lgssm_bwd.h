@@ -157,17 +157,26 @@ KV_DEV void filter_bwd_seed(const D d, const kvae_lgssm_problem &P, const kvae_l
   KV_SYNC();
 }
 
+// The filter adjoint as three pieces, so that a caller can interleave other work between time steps (the fused
+// alpha-network backward of kvae_lgssm_wide.hip): begin -> step(T-1) ... step(0) -> end.
 template <class D>
-KV_DEV void filter_bwd_sweep(const D d, const kvae_lgssm_problem &P, const kvae_lgssm_states &S,
-                             const kvae_lgssm_input_grads &G, const float *ws, int b, BwdLds<D> &L) {
-  const int n = d.n(), m = d.m(), p = d.p(), T = P.T, nn = n * n, rec = 2 * (n + nn);
-  const int64_t bT = (int64_t)b * T;
+KV_DEV void filter_bwd_begin(const D d, const kvae_lgssm_problem &P, BwdLds<D> &L) {
+  const int n = d.n(), p = d.p(), nn = n * n;
   copy_in(L.R, P.R, p * p);
   KV_LANE0 { L.mk[0] = 1.0f; }
   KV_PAR(i, n) { L.gmu[i] = 0.0f; }
   KV_PAR(e, nn) { L.gSig[e] = 0.0f; }
   KV_SYNC();
-  for (int t = T - 1; t >= 0; --t) {
+}
+
+// One step of the filter adjoint: consumes the carried (gmu, gSig) of step t+1 and the hand-off record ws[b,t], writes
+// gA/gB/gC/gQ/gY/gU of step t and leaves (gmu, gSig) for step t-1.  On return L.mup / L.C / L.mk hold step t's values.
+template <class D>
+KV_DEV void filter_bwd_step(const D d, const kvae_lgssm_problem &P, const kvae_lgssm_states &S,
+                            const kvae_lgssm_input_grads &G, const float *ws, int b, int t, BwdLds<D> &L) {
+  const int n = d.n(), m = d.m(), p = d.p(), T = P.T, nn = n * n, rec = 2 * (n + nn);
+  const int64_t bT = (int64_t)b * T;
+  {
     const int64_t q = bT + t;
     const float *w = ws + q * rec;
     operands_load(d, P, b, t, L);
@@ -342,8 +351,21 @@ KV_DEV void filter_bwd_sweep(const D d, const kvae_lgssm_problem &P, const kvae_
     }
     KV_SYNC();
   }
+}
+
+template <class D>
+KV_DEV void filter_bwd_end(const D d, const kvae_lgssm_input_grads &G, int b, BwdLds<D> &L) {
+  const int n = d.n(), nn = n * n;
   if (G.g_mu0) copy_out(G.g_mu0 + (int64_t)b * n, L.gmu, n);
   if (G.g_Sigma0) copy_out(G.g_Sigma0 + (int64_t)b * nn, L.gSig, nn);
+}
+
+template <class D>
+KV_DEV void filter_bwd_sweep(const D d, const kvae_lgssm_problem &P, const kvae_lgssm_states &S,
+                             const kvae_lgssm_input_grads &G, const float *ws, int b, BwdLds<D> &L) {
+  filter_bwd_begin(d, P, L);
+  for (int t = P.T - 1; t >= 0; --t) filter_bwd_step(d, P, S, G, ws, b, t, L);
+  filter_bwd_end(d, G, b, L);
 }
 
 }  // namespace kvae

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -45,7 +45,7 @@ class InputGrads(C.Structure):  # kvae_lgssm_input_grads
                 ("gY", C.c_void_p), ("gU", C.c_void_p), ("g_mu0", C.c_void_p), ("g_Sigma0", C.c_void_p)]
 
 
-SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
+SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_alpha_lstm_bwd", "kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
            "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_lstm_fwd",
            "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
@@ -71,8 +71,10 @@ class LgssmLib:
         for name in ("kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd"):
             getattr(d, name).argtypes = [P, S, vp]
             getattr(d, name).restype = C.c_int
-        d.kvae_lgssm_filter_alpha_lstm.argtypes = [P, S] + [vp] * 9 + [C.c_int32, C.c_int32, vp, vp, vp]
+        d.kvae_lgssm_filter_alpha_lstm.argtypes = [P, S] + [vp] * 9 + [C.c_int32, C.c_int32] + [vp] * 7
         d.kvae_lgssm_filter_alpha_lstm.restype = C.c_int
+        d.kvae_lgssm_alpha_lstm_bwd.argtypes = [P, S, S, G, vp, C.c_int] + [vp] * 6 + [C.c_int32, C.c_int32] + [vp] * 9
+        d.kvae_lgssm_alpha_lstm_bwd.restype = C.c_int
         d.kvae_lgssm_smooth_bwd.argtypes = [P, S, S, G, vp, C.c_int, vp]
         d.kvae_lgssm_smooth_bwd.restype = C.c_int
         d.kvae_lgssm_elbo.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, G, vp]

@@ -47,8 +47,8 @@ class KalmanFilter(nn.Module):
         if mask is None:
             return True
         if mask.is_cuda and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("lstm dynamics with an explicit mask needs a host check of the mask; "
-                               "pass mask=None (all frames observed) inside hipGraph capture")
+            raise RuntimeError("lstm dynamics with an explicit mask on a shape outside the in-kernel alpha-network "
+                               "(hidden 50, a_dim 2, K <= 16) needs a host check of the mask; pass mask=None inside capture")
         return bool((mask != 0).all())
 
     def _operands(self, Y, mask):
@@ -125,27 +125,31 @@ class KalmanFilter(nn.Module):
             from .. import _native
             _native.lib_for(Y)  # raises: no CPU fallback (unless a test injected the host simulator)
         mask = self._mask(mask, Y)
-        ops = self._operands(Y, mask)
-        if ops is None and Y.is_cuda and not (torch.is_grad_enabled() and (Y.requires_grad or any(
-                q.requires_grad for q in self.dyn_params.parameters()))):
-            # lstm + missing frames, no gradients wanted (imputation / evaluation): alpha-network inside the kernel
-            dyn = self.dyn_params
-            res = lgssm_ops.alpha_lstm_filter(Y, U, mask, dyn.lstm, dyn.head_w, dyn.A, dyn.B, dyn.C, self.Q, self.R,
-                                              self.mu0, self.Sigma0)
-            if res is not None:
-                mf, Sf, mp, Sp, rec, slots, alpha = res
-                n, m, p = self.n, self.m, self.p
-                views = (rec[..., :n * n].unflatten(-1, (n, n)), rec[..., n * n:n * n + n * m].unflatten(-1, (n, m)),
-                         rec[..., n * n + n * m:].unflatten(-1, (p, n)))
-                dyn.state_seq = alpha
-                self._last = dict(rec=rec, slots=slots, A=None, B=None, C=None, Q=self.Q, views=views, Q_view=None)
-                u1 = lambda v: v.unsqueeze(-1)
-                if not with_rts:
-                    return None, None, u1(mf), Sf, u1(mp), Sp
-                ms, Ss = lgssm_ops.rts_only(Y, U, mask, rec, None, None, None, self.Q, self.R, self.mu0, self.Sigma0, slots,
-                                            mf, Sf, mp, Sp)
+        dyn = self.dyn_params
+        u1 = lambda v: v.unsqueeze(-1)
+        if (mask is not None and not dyn.is_switching_dynamics and dyn.K > 1
+                and lgssm_ops.alpha_lstm_supported(Y, dyn.lstm, dyn.K)):
+            # lstm dynamics with an explicit mask: the alpha-network runs inside the filter kernel, forward AND backward
+            # (kvae_lgssm_filter_alpha_lstm / kvae_lgssm_alpha_lstm_bwd).  Whether the mask hides anything is never asked
+            # on the host: no sync, capturable, and a mask of ones (the reference's training loop) gives the same numbers
+            # as the precomputed-alpha path.
+            outs = lgssm_ops.AlphaLstmSmooth.apply(Y, U, mask, dyn.lstm.weight_ih_l0, dyn.lstm.weight_hh_l0, dyn.lstm.bias_ih_l0,
+                                                   dyn.lstm.bias_hh_l0, dyn.head_w.weight, dyn.head_w.bias, dyn.A, dyn.B, dyn.C,
+                                                   self.Q, self.R, self.mu0, self.Sigma0, with_rts)
+            rec, alpha = outs[-2], outs[-1]
+            n, m, p = self.n, self.m, self.p
+            views = (rec[..., :n * n].unflatten(-1, (n, n)), rec[..., n * n:n * n + n * m].unflatten(-1, (n, m)),
+                     rec[..., n * n + n * m:].unflatten(-1, (p, n)))
+            dyn.state_seq = alpha
+            self._last = dict(rec=rec, slots=Slots(A=0, B=n * n, C=n * n + n * m), A=None, B=None, C=None, Q=self.Q,
+                              views=views, Q_view=None)
+            if with_rts:
+                ms, Ss, mf, Sf, mp, Sp = outs[:6]
                 return u1(ms), Ss, u1(mf), Sf, u1(mp), Sp
-        if ops is None:  # lstm + missing frames (training with masks, or shapes outside the fused kernel)
+            mf, Sf, mp, Sp = outs[:4]
+            return None, None, u1(mf), Sf, u1(mp), Sp
+        ops = self._operands(Y, mask)
+        if ops is None:  # lstm + missing frames on shapes outside the fused kernel (or host tensors in the test tier)
             mf, Sf, mp, Sp, A_l, B_l, C_l = self._filter_stepwise(Y, U, mask)
             self._last = dict(rec=None, slots=_NO_SLOTS, A=A_l, B=B_l, C=C_l, Q=self.Q, views=(A_l, B_l, C_l),
                               Q_view=None)
@@ -155,17 +159,15 @@ class KalmanFilter(nn.Module):
             # "given operands" form by re-running filter+RTS in one launch on the per-step stacks
             ms, Ss, mf, Sf, mp, Sp = LgssmSmooth.apply(Y, U, mask, None, A_l, B_l, C_l, self.Q, self.R, self.mu0,
                                                        self.Sigma0, _NO_SLOTS, True)
-            u = lambda v: v.unsqueeze(-1)
-            return u(ms), Ss, u(mf), Sf, u(mp), Sp
+            return u1(ms), Ss, u1(mf), Sf, u1(mp), Sp
         self._last = ops
         outs = LgssmSmooth.apply(Y, U, mask, ops["rec"], ops["A"], ops["B"], ops["C"], ops["Q"], self.R, self.mu0,
                                  self.Sigma0, ops["slots"], with_rts)
-        u = lambda v: v.unsqueeze(-1)
         if with_rts:
             ms, Ss, mf, Sf, mp, Sp = outs
-            return u(ms), Ss, u(mf), Sf, u(mp), Sp
+            return u1(ms), Ss, u1(mf), Sf, u1(mp), Sp
         mf, Sf, mp, Sp = outs
-        return None, None, u(mf), Sf, u(mp), Sp
+        return None, None, u1(mf), Sf, u1(mp), Sp
 
     def filter(self, Y, U, mask=None):
         _, _, mf, Sf, mp, Sp = self._run(Y, U, mask, with_rts=False)

@@ -415,34 +415,103 @@ class BiGruSequence(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
-# masked sequences with the LSTM alpha-network: filter with the network inside the kernel (no autograd)
+# masked sequences with the LSTM alpha-network: the network runs INSIDE the filter kernel, forward and backward
 # ------------------------------------------------------------------------------------------------
 ALPHA_LSTM_SUPPORTED = dict(hidden=50, p=2, max_K=16)
 
 
-@torch.no_grad()
-def alpha_lstm_filter(Y, U, mask, lstm, head, A, Bm, Cm, Q, R, mu0, Sigma0):
-    """Kalman filter whose per-step alpha comes from an LSTM fed with C mu_{t|t-1} on hidden frames (reference
-    kalman_filter.py:151-185 + dyn_param.py:39-63) in ONE launch. Returns (mf, Sf, mp, Sp, record, slots, alpha)."""
-    Y, U, mask = _f32c(Y), _f32c(U), _f32c(mask)
-    Bsz, T, p = Y.shape
-    K, n, m = A.shape[0], A.shape[1], Bm.shape[2]
-    E = n * n + n * m + p * n
-    dev = Y.device
-    mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-    mf, Sf, mp, Sp = mk(Bsz, T, n), mk(Bsz, T, n, n), mk(Bsz, T, n), mk(Bsz, T, n, n)
-    record, alpha = mk(Bsz, T, E), mk(Bsz, T, K)
-    slots = Slots(A=0, B=n * n, C=n * n + n * m)
-    call = _Call(Y, U, mask, record, None, None, None, Q, R, mu0, Sigma0, slots)
-    ws = [_f32c(t.detach()) for t in (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, head.weight,
-                                      head.bias, A, Bm, Cm)]
-    st = _states(mf, Sf, mp, Sp)
-    rc = call.lib.dll.kvae_lgssm_filter_alpha_lstm(C.byref(call.prob), C.byref(st), *[N.ptr(w) for w in ws], K,
-                                                   lstm.hidden_size, N.ptr(record), N.ptr(alpha), call.stream)
-    if rc == 1:
-        return None   # shape outside the kernel's limits: caller keeps the per-step path
-    call.lib.check(rc, "kvae_lgssm_filter_alpha_lstm")
-    return mf, Sf, mp, Sp, record, slots, alpha
+def alpha_lstm_supported(Y, lstm, K):
+    """Shapes csrc/kvae_lgssm_wide.hip instantiates the in-kernel alpha-network for (KVAEConfig defaults)."""
+    return (Y.is_cuda and K > 1 and K <= ALPHA_LSTM_SUPPORTED["max_K"] and lstm.hidden_size == ALPHA_LSTM_SUPPORTED["hidden"]
+            and Y.shape[-1] == ALPHA_LSTM_SUPPORTED["p"] and lstm.input_size == Y.shape[-1])
+
+
+class AlphaLstmSmooth(torch.autograd.Function):
+    """Kalman filter (+ RTS smoother) whose per-step alpha comes from an LSTM fed with y_{t-1}, or with C mu_{t|t-1} on
+    hidden frames (reference kalman_filter.py:151-185 + dyn_param.py:39-63): ONE launch forward (+ one for the smoother),
+    ONE launch backward - the coupled adjoint of filter and cell (kvae_lgssm_alpha_lstm_bwd) - instead of T cell steps
+    and T single-step filter launches each way.  Returns (ms, Ss,) mf, Sf, mp, Sp, record [B,T,A|B|C], alpha [B,T,K]."""
+
+    @staticmethod
+    def forward(ctx, Y, U, mask, w_ih, w_hh, b_ih, b_hh, head_w, head_b, A, Bm, Cm, Q, R, mu0, Sigma0, with_rts):
+        Y, U, mask = _f32c(Y), _f32c(U), _f32c(mask)
+        ws_ = [_f32c(t.detach()) for t in (w_ih, w_hh, b_ih, b_hh, head_w, head_b, A, Bm, Cm)]
+        Bsz, T, p = Y.shape
+        K, n, m = A.shape[0], A.shape[1], Bm.shape[2]
+        H = w_hh.shape[1]
+        E = n * n + n * m + p * n
+        dev = Y.device
+        mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        mf, Sf, mp, Sp = mk(Bsz, T, n), mk(Bsz, T, n, n), mk(Bsz, T, n), mk(Bsz, T, n, n)
+        record, alpha = mk(Bsz, T, E), mk(Bsz, T, K)
+        need = any(ctx.needs_input_grad)
+        gates, c_seq, h_seq, x_seq = (mk(Bsz, T, 4 * H), mk(Bsz, T, H), mk(Bsz, T, H), mk(Bsz, T, p)) if need else (None,) * 4
+        slots = Slots(A=0, B=n * n, C=n * n + n * m)
+        call = _Call(Y, U, mask, record, None, None, None, Q, R, mu0, Sigma0, slots)
+        ms, Ss = (mk(Bsz, T, n), mk(Bsz, T, n, n)) if with_rts else (None, None)
+        st = _states(mf, Sf, mp, Sp, ms, Ss)
+        call.lib.check(N.timed("alpha_lstm_fwd", Y, lambda: call.lib.dll.kvae_lgssm_filter_alpha_lstm(
+            C.byref(call.prob), C.byref(st), *[N.ptr(w) for w in ws_], K, H, N.ptr(record), N.ptr(alpha), N.ptr(gates),
+            N.ptr(c_seq), N.ptr(h_seq), N.ptr(x_seq), call.stream)), "kvae_lgssm_filter_alpha_lstm")
+        if with_rts:
+            call.lib.check(call.lib.dll.kvae_lgssm_rts_fwd(C.byref(call.prob), C.byref(st), call.stream), "kvae_lgssm_rts_fwd")
+        ctx.with_rts, ctx.slots = with_rts, slots
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(Y, U, mask, *ws_, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss, record, alpha, gates, c_seq, h_seq, x_seq)
+        return ((ms, Ss) if with_rts else ()) + (mf, Sf, mp, Sp, record, alpha)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        (Y, U, mask, w_ih, w_hh, b_ih, b_hh, head_w, head_b, A, Bm, Cm, Q, R, mu0, Sigma0, mf, Sf, mp, Sp, ms, Ss, record, alpha,
+         gates, c_seq, h_seq, x_seq) = ctx.saved_tensors
+        with_rts, slots = ctx.with_rts, ctx.slots
+        if with_rts:
+            g_ms, g_Ss, g_mf, g_Sf, g_mp, g_Sp, g_rec, g_alpha = (_f32c(g) for g in gouts)
+        else:
+            g_mf, g_Sf, g_mp, g_Sp, g_rec, g_alpha = (_f32c(g) for g in gouts)
+            g_ms = g_Ss = None
+        call = _Call(Y, U, mask, record, None, None, None, Q, R, mu0, Sigma0, slots)
+        Bsz, T, n, m, p = call.dims
+        K, H = A.shape[0], w_hh.shape[1]
+        dev = Y.device
+        need = ctx.needs_input_grad
+        sink = _GradSink(call, record, None, None, None, Q, slots, False)   # gA|gB|gC land in one g_record buffer
+        g0 = S0 = None
+        if need[14]:
+            g0 = torch.empty(Bsz, n, device=dev, dtype=torch.float32)
+            sink.g.g_mu0 = g0.data_ptr()
+        if need[15]:
+            S0 = torch.empty(Bsz, n, n, device=dev, dtype=torch.float32)
+            sink.g.g_Sigma0 = S0.data_ptr()
+        ws = torch.empty(Bsz, T, 2 * (n + n * n), device=dev, dtype=torch.float32)
+        d_pre = torch.empty(Bsz, T, 4 * H, device=dev, dtype=torch.float32)
+        g_logit = torch.empty(Bsz, T, K, device=dev, dtype=torch.float32)
+        saved = _states(mf, Sf, mp, Sp, ms, Ss)
+        up = _states(g_mf, g_Sf, g_mp, g_Sp, g_ms, g_Ss)
+        call.lib.check(N.timed("alpha_lstm_bwd", Y, lambda: call.lib.dll.kvae_lgssm_alpha_lstm_bwd(
+            C.byref(call.prob), C.byref(saved), C.byref(up), C.byref(sink.g), N.ptr(ws), int(with_rts), N.ptr(w_ih), N.ptr(w_hh),
+            N.ptr(head_w), N.ptr(A), N.ptr(Bm), N.ptr(Cm), K, H, N.ptr(alpha), N.ptr(gates), N.ptr(c_seq), N.ptr(g_rec),
+            N.ptr(g_alpha), N.ptr(sink.gpacked), N.ptr(d_pre), N.ptr(g_logit), call.stream)), "kvae_lgssm_alpha_lstm_bwd")
+        # parameter gradients: reductions over (b,t) of what the launch wrote
+        d2 = d_pre.reshape(Bsz * T, 4 * H)
+        h_prev = torch.cat([h_seq.new_zeros(Bsz, 1, H), h_seq[:, :-1]], dim=1).reshape(Bsz * T, H)
+        g_whh, g_wih, g_b = d2.t() @ h_prev, d2.t() @ x_seq.reshape(Bsz * T, p), N.colsum(d2)
+        gl2 = g_logit.reshape(Bsz * T, K)
+        g_hw, g_hb = gl2.t() @ h_seq.reshape(Bsz * T, H), N.colsum(gl2)
+        base = torch.cat([t.reshape(K, -1) for t in (A, Bm, Cm)], dim=1)
+        nblk = call.lib.dll.kvae_mix_bwd_partials(Bsz * T)
+        E = base.shape[1]
+        partials = torch.empty(nblk, K, E, device=dev, dtype=torch.float32)
+        g_alpha_scratch, g_base = torch.empty_like(alpha), torch.empty_like(base)
+        call.lib.check(call.lib.dll.kvae_mix_bwd(N.ptr(alpha), N.ptr(base), N.ptr(sink.gpacked), N.ptr(g_alpha_scratch), N.ptr(g_base),
+                                                 N.ptr(partials), Bsz * T, K, E, 0, call.stream), "kvae_mix_bwd")
+        gA, gB, gC = g_base.split([n * n, n * m, p * n], dim=1)
+        if g0 is not None and mu0.dim() == 1:
+            g0 = N.colsum(g0)
+        if S0 is not None and Sigma0.dim() == 2:
+            S0 = N.colsum(S0)
+        return (sink.gY if need[0] else None, sink.gU if need[1] else None, None, g_wih, g_whh, g_b, g_b, g_hw, g_hb,
+                gA.reshape(A.shape), gB.reshape(Bm.shape), gC.reshape(Cm.shape), None, None, g0, S0, None)
 
 
 @torch.no_grad()

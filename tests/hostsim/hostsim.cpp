@@ -310,7 +310,14 @@ int kvae_bce_frames_bwd(const float *logits, const float *x, const float *g_fram
 // that the Python side keeps the per-step path on host tensors.
 extern "C" int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *, const kvae_lgssm_states *, const float *, const float *,
                                             const float *, const float *, const float *, const float *, const float *,
-                                            const float *, const float *, int32_t, int32_t, float *, float *, void *) {
+                                            const float *, const float *, int32_t, int32_t, float *, float *, float *, float *,
+                                            float *, float *, void *) {
+  return KVAE_ERR_DIMS;
+}
+extern "C" int kvae_lgssm_alpha_lstm_bwd(const kvae_lgssm_problem *, const kvae_lgssm_states *, const kvae_lgssm_states *,
+                                         const kvae_lgssm_input_grads *, float *, int, const float *, const float *, const float *,
+                                         const float *, const float *, const float *, int32_t, int32_t, const float *, const float *,
+                                         const float *, const float *, const float *, float *, float *, float *, void *) {
   return KVAE_ERR_DIMS;
 }
 

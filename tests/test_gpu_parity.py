@@ -107,9 +107,16 @@ def test_train_step_gpu(name, kind):
 
 @pytest.mark.parametrize("B,T,n,m,p,K", [(256, 50, 4, 4, 2, 3), (7, 33, 4, 4, 2, 3), (5, 17, 3, 2, 1, 2),
                                          (3, 9, 8, 5, 3, 4), (64, 200, 16, 16, 2, 3), (1, 1, 4, 4, 2, 3),
-                                         (2, 2, 16, 16, 2, 1)])
+                                         (2, 2, 16, 16, 2, 1), (512, 200, 16, 16, 2, 3), (8, 200, 16, 16, 2, 3),
+                                         (5, 1, 16, 16, 2, 2)])
 def test_vs_oracle_random(B, T, n, m, p, K):
+    """Values vs the C oracle at every size, incl. the FULL BASELINE configs[4] shard (512, 200, 16); gradients vs the
+    torch oracle's autograd up to configs[1] size (256, 50, 4) and for n = 16 at (8, 200, 16)."""
     parity_cases.vs_oracle_random(DEV, B, T, n, m, p, K)
+
+
+def test_n16_generic_fallback():
+    parity_cases.n16_generic_fallback(DEV)
 
 
 def test_linearity_full_size():
@@ -260,30 +267,83 @@ def test_bce_frames_gpu(shape):
     parity_cases.bce_frames_vs_torch(DEV, *shape)
 
 
-@pytest.mark.parametrize("K,T", [(3, 20), (7, 100)])
-def test_alpha_lstm_masked_matches_stepwise(K, T):
-    """In-kernel alpha-network filter (no-grad path) == the per-step differentiable path, masked frames."""
+@pytest.mark.parametrize("K,T,n", [(3, 20, 4), (7, 60, 4), (2, 12, 16)])
+def test_alpha_lstm_masked_matches_stepwise(K, T, n):
+    """Masked frames with the lstm alpha-net: the in-kernel path (network inside the filter kernel, coupled adjoint in
+    ONE backward launch) against the product's per-step differentiable path (T nn.LSTM cell steps + T single-step filter
+    launches, autograd through all of it) - values, alpha, and every gradient.  The goldens masked_lstm_* pin the same
+    path to the reference itself (test_latent_gpu)."""
+    from kvae.kalman.lgssm_ops import LgssmSmooth, Slots
     from kvae.model.model import KVAE
     from kvae.utils.config import KVAEConfig
     torch.manual_seed(K)
-    model = KVAE(KVAEConfig(dynamics_model="lstm", num_modes=K))
+    model = KVAE(KVAEConfig(dynamics_model="lstm", num_modes=K, z_dim=n))
     with torch.no_grad():
         model.kalman_filter.dyn_params.A.add_(0.05 * torch.randn_like(model.kalman_filter.dyn_params.A))
         model.kalman_filter.dyn_params.head_w.bias.zero_()
         model.kalman_filter.dyn_params.head_w.weight.mul_(3.0)
-    kf = model.kalman_filter.to(DEV).eval()
+    kf = model.kalman_filter.to(DEV).train()
+    dyn = kf.dyn_params
     B = 5
     a = torch.randn(B, T, 2, device=DEV)
-    u = torch.zeros(B, T, 4, device=DEV)
+    u = 0.3 * torch.randn(B, T, n, device=DEV)
     mask = (torch.rand(B, T, device=DEV) > 0.4).float()
     mask[:, :3] = 1.0
+    w_ms, w_Ss = torch.randn(B, T, n, 1, device=DEV), torch.randn(B, T, n, n, device=DEV)
+    w_mf = torch.randn(B, T, n, 1, device=DEV)
+    params = list(dyn.parameters())
+
+    def loss_of(outs):
+        ms, Ss, mf = outs[0], outs[1], outs[2]
+        A_l, C_l = outs[6], outs[8]
+        return (ms * w_ms).sum() + (Ss * w_Ss).sum() + (mf * w_mf).sum() + 0.1 * (A_l ** 2).sum() + 0.1 * (C_l ** 2).sum()
+
+    a_f = a.clone().requires_grad_(True)
+    dyn.reset_state()
+    fast = kf.smooth(a_f, u, mask=mask)                       # in-kernel alpha-network
+    alpha_fast = dyn.state_seq.detach().clone()
+    g_fast = torch.autograd.grad(loss_of(fast), [a_f] + params, allow_unused=True)
+
+    a_s = a.clone().requires_grad_(True)
+    dyn.reset_state()
+    mf, Sf, mp, Sp, A_l, B_l, C_l = kf._filter_stepwise(a_s, u, mask)     # reference-shaped per-step path
+    ms, Ss, mf2, Sf2, mp2, Sp2 = LgssmSmooth.apply(a_s, u, mask, None, A_l, B_l, C_l, kf.Q, kf.R, kf.mu0, kf.Sigma0, Slots(), True)
+    slow = (ms.unsqueeze(-1), Ss, mf2.unsqueeze(-1), Sf2, mp2.unsqueeze(-1), Sp2, A_l, B_l, C_l)
+    alpha_slow = dyn.state_seq.detach()
+    g_slow = torch.autograd.grad(loss_of(slow), [a_s] + params, allow_unused=True)
+
+    assert rel_err(alpha_fast.cpu(), alpha_slow.cpu()) < 2e-4
+    for f_, s_ in zip(fast, slow):
+        assert rel_err(f_.detach().cpu(), s_.detach().cpu()) < 5e-4
+    names = ["a"] + [k for k, _ in dyn.named_parameters()]
+    for name, gf, gs in zip(names, g_fast, g_slow):
+        assert (gf is None) == (gs is None), name
+        if gf is not None:
+            assert rel_err(gf.cpu(), gs.cpu()) < 3e-3, name
+
+
+def test_explicit_ones_mask_equals_no_mask():
+    """The reference's loop passes mask = ones (train.py:41): with lstm dynamics that takes the in-kernel alpha-network
+    (no host-side inspection of the mask) and must reproduce the precomputed-alpha path of mask=None."""
+    from kvae.model.model import KVAE
+    from kvae.utils.config import KVAEConfig
+    torch.manual_seed(0)
+    model = KVAE(KVAEConfig(dynamics_model="lstm", num_modes=3))
     with torch.no_grad():
+        model.kalman_filter.dyn_params.A.add_(0.05 * torch.randn_like(model.kalman_filter.dyn_params.A))
+        model.kalman_filter.dyn_params.head_w.bias.zero_()
+    kf = model.kalman_filter.to(DEV).train()
+    a = torch.randn(6, 15, 2, device=DEV)
+    u = torch.zeros(6, 15, 4, device=DEV)
+    outs = []
+    for mk in (None, torch.ones(6, 15, device=DEV)):
+        ar = a.clone().requires_grad_(True)
         kf.dyn_params.reset_state()
-        fast = kf.smooth(a, u, mask=mask)
-        alpha_fast = kf.dyn_params.state_seq.clone()
-    a_g = a.clone().requires_grad_(True)     # grad-enabled call takes the per-step path
-    kf.dyn_params.reset_state()
-    slow = kf.smooth(a_g, u, mask=mask)
-    assert rel_err(alpha_fast.cpu(), kf.dyn_params.state_seq.detach().cpu()) < 2e-4
-    for f, s_ in zip(fast, slow):
-        assert rel_err(f.cpu(), s_.detach().cpu()) < 5e-4
+        o = kf.smooth(ar, u, mask=mk)
+        g = torch.autograd.grad(o[0].sum() + (o[1] ** 2).sum(), [ar] + list(kf.dyn_params.parameters()), allow_unused=True)
+        outs.append((o, g))
+    for x, y in zip(outs[0][0], outs[1][0]):
+        assert rel_err(y.detach().cpu(), x.detach().cpu()) < 2e-4
+    for x, y in zip(outs[0][1], outs[1][1]):
+        if x is not None:
+            assert rel_err(y.cpu(), x.cpu()) < 2e-3

@@ -116,7 +116,7 @@ def test_device_batches_on_gpu_match_items(tmp_path, resident):
     p = tmp_path / "d.npz"
     np.savez_compressed(p, images=rng.integers(0, 256, size=(13, 6, 32, 32), dtype=np.uint8))
     ds = PymunkNPZDataset.from_npz(str(p), seq_len=6, state_key=None)
-    loader = DeviceBatches(ds, 4, DEV, shuffle=True, seed=7, resident=resident)
+    loader = DeviceBatches(ds, 4, DEV, shuffle=True, seed=7, resident=resident, drop_last=False)
     assert loader.resident is resident
     order = torch.randperm(13, generator=torch.Generator().manual_seed(7))
     seen = 0
