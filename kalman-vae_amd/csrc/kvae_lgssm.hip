@@ -89,7 +89,10 @@ __global__ __launch_bounds__(64) void k_elbo_probe(kvae_lgssm_problem P, const f
 template <class D>
 __global__ __launch_bounds__(64) void k_elbo(kvae_lgssm_problem P, const float *mus, const float *Sigs,
                                              const float *eps, float *terms, const int32_t *levels, const float *ws,
-                                             float *g_mus, float *g_Sigs, kvae_lgssm_input_grads G, int have_g) {
+                                             float *g_mus, float *g_Sigs, kvae_lgssm_input_grads G, int have_g,
+                                             int only_if_jitter) {
+  // only_if_jitter: this launch backs up a level-0-only fast kernel (lgssm_n16_elbo.h) that has already run
+  if (only_if_jitter && levels[0] == 0 && levels[1] == 0) return;
   __shared__ ElboLds<D> L;
   const D d(P.n, P.m, P.p);
   const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
@@ -179,6 +182,11 @@ extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgs
 extern "C" void kvae_n16_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                     hipStream_t s);
 
+extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
+                                           float *zst, int32_t *levels, hipStream_t s);
+extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
+                                     float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
+                                     const kvae_lgssm_input_grads *g, int have_g, hipStream_t s);
 extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                                     const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s);
 
@@ -337,12 +345,28 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
                          g_Sigmas, want_g ? g : &gz, want_g ? 1 : 0, s);
     return launch_status("k_elbo_tpp");
   }
+  if (n16_ok(prob) && ws_lz && aligned16(mus_smooth) && aligned16(Sigmas_smooth) && aligned16(eps) && aligned16(ws_lz) &&
+      (!want_g || (aligned16(g_Sigmas) && aligned16(g->gA.ptr) && g->gA.sb % 4 == 0 && g->gA.st % 4 == 0 && aligned16(g->gB.ptr) &&
+                   g->gB.sb % 4 == 0 && g->gB.st % 4 == 0))) {
+    // matrix-core / four-matrices-per-wavefront kernels (lgssm_n16_elbo.h): the probe resolves the jitter levels with the
+    // generic semantics; the fast main launch computes the call when both are 0, the generic one when they are not
+    kvae_n16_launch_elbo_probe(prob, Sigmas_smooth, mus_smooth, eps, ws_lz, chol_levels, s);
+    rc = launch_status("k_elbo_probe_n16");
+    if (rc) return rc;
+    kvae_n16_launch_elbo(prob, mus_smooth, Sigmas_smooth, eps, terms, chol_levels, ws_lz, g_mus, g_Sigmas, want_g ? g : &gz,
+                         want_g ? 1 : 0, s);
+    rc = launch_status("k_elbo_n16");
+    if (rc) return rc;
+    k_elbo<SDims<16, 16, 2>><<<dim3(grid), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps, terms, (const int32_t *)chol_levels,
+                                                            nullptr, g_mus, g_Sigmas, want_g ? *g : gz, want_g ? 1 : 0, 1);
+    return launch_status("k_elbo(jitter fallback)");
+  }
   KVAE_DISPATCH(*prob, k_elbo_probe<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, Sigmas_smooth, mus_smooth, eps, ws_lz, chol_levels));
   rc = launch_status("k_elbo_probe");
   if (rc) return rc;
   KVAE_DISPATCH(*prob, k_elbo<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps,
                                            terms, (const int32_t *)chol_levels, (const float *)ws_lz, g_mus, g_Sigmas, want_g ? *g : gz,
-                                           want_g ? 1 : 0));
+                                           want_g ? 1 : 0, 0));
   return launch_status("k_elbo");
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lgssm_n16.h"
+#include "lgssm_n16_elbo.h"
 
 using namespace kvae;
 
@@ -44,4 +45,32 @@ extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgss
   else if (has_fp) k_smooth_bwd_n16<true, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
   else if (gq) k_smooth_bwd_n16<false, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
   else k_smooth_bwd_n16<false, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
+}
+
+// ---- ELBO terms (lgssm_n16_elbo.h): grid = B*T, one wavefront per (sequence, step) ------------------------------------
+__global__ __launch_bounds__(64) void k_elbo_probe_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
+                                                       float *zst, int32_t *levels) {
+  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
+  n16::elbo_probe(P, Sig_s, mus, eps, zst, levels, b, t);
+}
+template <bool GRADS, bool HAS_GQ>
+__global__ __launch_bounds__(64) void k_elbo_n16(kvae_lgssm_problem P, const float *mus, const float *Sigs, const float *eps,
+                                                 float *terms, const int32_t *levels, const float *zst, float *g_mus,
+                                                 float *g_Sigs, kvae_lgssm_input_grads G) {
+  __shared__ n16::ELds L;
+  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
+  n16::elbo_main<GRADS, HAS_GQ>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t, L);
+}
+
+extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
+                                           float *zst, int32_t *levels, hipStream_t s) {
+  k_elbo_probe_n16<<<dim3((unsigned)((int64_t)p->B * p->T)), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
+}
+extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
+                                     float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
+                                     const kvae_lgssm_input_grads *g, int have_g, hipStream_t s) {
+  const dim3 grid((unsigned)((int64_t)p->B * p->T)), block(64);
+  if (!have_g) k_elbo_n16<false, false><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
+  else if (g->gQ.ptr) k_elbo_n16<true, true><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
+  else k_elbo_n16<true, false><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
 }

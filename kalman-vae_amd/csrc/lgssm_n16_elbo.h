@@ -1,0 +1,318 @@
+// lgssm_n16_elbo.h — the LGSSM terms of the sampled ELBO and their gradients for (n, m, p) = (16, 16, 2), one wavefront
+// per (sequence, step) as in lgssm_elbo.h (same equations, cited there), but with the four 16-lane row-groups of the
+// wavefront working on FOUR MATRICES AT ONCE, each with its rows on the lanes (lane i of a group owns row i, 16 registers):
+//
+//     group 0: Sigma_s[t]      group 1: Q_t (transition into t)      group 2: Q_{t+1}      group 3: Sigma0 (t = 0 only)
+//
+// One instruction stream factorises all four (right-looking Cholesky: the column broadcast is a DPP row_newbcast folded
+// into the fma), forward- and back-substitutes the four residuals (wv, d_t, d_{t+1}, z_0 - mu0), and inverts the two
+// factors the gradients need.  Nothing here is serial on one lane (the generic body solves its triangular systems on lane
+// 0).  The 16x16x16 products of the Cholesky backward, g Sigma_s = sym(L^-T Phi L^-1), and of g Q_t run on the matrix cores
+// in the C-layout of lgssm_n16.h after one hop through LDS.
+//
+// _safe_cholesky (kalman_filter.py:282-302): the probe launch resolves the whole-batch jitter level exactly as the generic
+// probe does (first level 0..4 whose factorisation has all pivots > 0, 5 = diagonal fallback) and parks z_t = mu_t + L_t eps_t
+// of level 0.  The main launch below handles level 0 for both families - the case of every sane model - and returns at once
+// otherwise; kvae_lgssm_elbo then runs the generic main kernel, which in turn returns at once when both levels are 0.
+#pragma once
+#include "lgssm_elbo.h"
+#include "lgssm_n16.h"
+
+#if !defined(KVAE_HOSTSIM) && !defined(KV_TPP)
+namespace kvae {
+namespace n16 {
+
+struct alignas(16) ELds {
+  float t[4][N * LD];   // one tile per row-group: rows-on-lanes -> C-layout
+  Lds s;                // symmetrisation
+};
+
+// acc += (lane C of src's row) * f  - the DPP source is a different register than the accumulator
+template <int C>
+__device__ __forceinline__ void fmac_bcast_src(float &acc, float src, float f) {
+  asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(f), "n"(C));
+}
+// two wait states between the VALU write of v and its next DPP read (the compiler cannot see into the asm above)
+__device__ __forceinline__ void dpp_guard(float &v) { asm volatile("s_nop 1" : "+v"(v)); }
+
+// Cholesky factor with its rows on the lanes
+struct Chol {
+  float l[N];    // row i of L (entries k <= i; garbage above the diagonal)
+  float lm[N];   // -L[i][k] / L[k][k] for i > k, else 0: the unit-lower factor, negated and masked for the substitutions
+  float rinv, ld;   // 1 / L[i][i], L[i][i]
+  bool bad;         // a pivot was not > 0 (uniform within the row-group)
+};
+template <int K, int C>
+__device__ __forceinline__ void chol_trail(float (&m)[N], float lk, float nl) {
+  if constexpr (C < N) {
+    fmac_bcast_src<C>(m[C], lk, nl);   // m[i][C] -= L[i][K] L[C][K]
+    chol_trail<K, C + 1>(m, lk, nl);
+  }
+}
+template <int K>
+__device__ __forceinline__ void chol_step(float (&m)[N], Chol &c, int i) {
+  const float d = bcast<K>(m[K]);
+  c.bad |= !(d > 0.0f);
+  const float ld = __builtin_amdgcn_sqrtf(d);
+  const float rinv = frcp(ld);
+  float lk = m[K] * rinv;                          // L[i][K] for i >= K
+  c.l[K] = i == K ? ld : lk;
+  c.lm[K] = i > K ? -(lk * rinv) : 0.0f;
+  if (i == K) c.rinv = rinv, c.ld = ld;
+  const float nl = -lk;
+  dpp_guard(lk);
+  chol_trail<K, K + 1>(m, lk, nl);
+  if constexpr (K + 1 < N) chol_step<K + 1>(m, c, i);
+}
+__device__ __forceinline__ void cholesky_rows(float (&m)[N], Chol &c, int i) {
+  c.bad = false, c.rinv = 0.f, c.ld = 1.f;
+  chol_step<0>(m, c, i);
+}
+
+// y = Lu^{-1} x in place (Lu = unit-lower part of L): L^{-1} x = y * rinv
+template <int K>
+__device__ __forceinline__ void fsub_step(const Chol &c, float &x) {
+  dpp_guard(x);
+  fmac_bcast<K>(x, c.lm[K]);
+  if constexpr (K + 2 < N) fsub_step<K + 1>(c, x);
+}
+// v = Lu^{-T} w in place
+template <int K>
+__device__ __forceinline__ void bsub_step(const Chol &c, float &v, int i) {
+  const float s = row_sum(c.lm[K] * v);            // -sum_{i > K} Lu[i][K] v[i]
+  v = i == K ? v + s : v;
+  if constexpr (K > 0) bsub_step<K - 1>(c, v, i);
+}
+
+// X = L^{-1} with its rows on the lanes
+template <int K, int C>
+__device__ __forceinline__ void inv_cols(const Chol &c, float (&y)[N]) {
+  if constexpr (C <= K) {
+    fmac_bcast<K>(y[C], c.lm[K]);                  // y[i][C] -= Lu[i][K] y[K][C]
+    inv_cols<K, C + 1>(c, y);
+  }
+}
+template <int K>
+__device__ __forceinline__ void inv_step(const Chol &c, float (&y)[N]) {
+  asm volatile("s_nop 1");                         // y[C] of the previous step -> DPP read
+  inv_cols<K, 0>(c, y);
+  if constexpr (K + 2 < N) inv_step<K + 1>(c, y);
+}
+__device__ __forceinline__ void inverse_rows(const Chol &c, float (&x)[N], int i) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] = i == k ? 1.0f : 0.0f;
+  inv_step<0>(c, x);
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] *= c.rinv;      // L^{-1} = D^{-1} Lu^{-1}
+}
+
+// rows-on-lanes (this group's tile) -> LDS; upper triangle cleared
+__device__ __forceinline__ void rows_to_tile(const float (&x)[N], float *tile, int i) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = 4 * q + r <= i ? x[4 * q + r] : 0.0f;
+    *reinterpret_cast<f4 *>(&tile[i * LD + 4 * q]) = v;
+  }
+}
+__device__ __forceinline__ f4 tile_c(const float *tile, int j, int g) {
+  return f4{tile[(4 * g + 0) * LD + j], tile[(4 * g + 1) * LD + j], tile[(4 * g + 2) * LD + j], tile[(4 * g + 3) * LD + j]};
+}
+
+// row i of sym(X) + jitter I (rows_only: the lower triangle as it is - what torch.linalg.cholesky reads)
+__device__ __forceinline__ void load_sym_rows(const float *X, float (&m)[N], int i, float jitter, bool rows_only) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4 v = *reinterpret_cast<const f4 *>(X + i * N + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * q + r;
+      const float xt = X[c * N + i];
+      m[c] = (rows_only ? v[r] : 0.5f * (v[r] + xt)) + (c == i ? jitter : 0.0f);
+    }
+  }
+}
+__device__ __forceinline__ void identity_rows(float (&m)[N], int i) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) m[c] = c == i ? 1.0f : 0.0f;
+}
+
+// acc = sum_c M[i][c] v[c] with row i of M on the lane (16-byte loads) and v in L-layout
+template <int C>
+__device__ __forceinline__ void matvec_rows_acc(float &acc, const float (&row)[N], float vL) {
+  if constexpr (C < N) {
+    fmac_bcast_src<C>(acc, vL, row[C]);
+    matvec_rows_acc<C + 1>(acc, row, vL);
+  }
+}
+__device__ __forceinline__ float matvec_rows(const float *M, float vL, int i) {
+  float row[N];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4 v = *reinterpret_cast<const f4 *>(M + i * N + 4 * q);
+    row[4 * q] = v[0], row[4 * q + 1] = v[1], row[4 * q + 2] = v[2], row[4 * q + 3] = v[3];
+  }
+  float acc = 0.0f;
+  dpp_guard(vL);
+  matvec_rows_acc<0>(acc, row, vL);
+  return acc;
+}
+
+// ---- probe: jitter levels + z_t = mu_t + chol(Sigma_s[t]) eps_t ------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void lower_matvec_acc(float &acc, const Chol &c, float epsL, int i) {
+  if constexpr (K < N) {
+    fmac_bcast_src<K>(acc, epsL, K <= i ? c.l[K] : 0.0f);
+    lower_matvec_acc<K + 1>(acc, c, epsL, i);
+  }
+}
+__device__ __forceinline__ void elbo_probe(const kvae_lgssm_problem &P, const float *Sig_s, const float *mus, const float *eps,
+                                           float *zst, int32_t *levels, int b, int t) {
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int64_t q = (int64_t)b * P.T + t;
+  const bool q_shared = P.Q.sb == 0 && P.Q.st == 0;
+  const bool probe_q = t >= 1 && (!q_shared || (b == 0 && t == 1));
+  const bool valid = g == 0 || (g == 1 && probe_q);
+  const float *X = g == 1 && probe_q ? stack_at(P.Q, b, t) : Sig_s + q * NN;
+  float m0[N], m[N];
+  load_sym_rows(X, m0, i, 0.0f, false);
+  // Every row-group climbs the same ladder as probe_level() - jitter 1e-6 * 10^level - and keeps the first level at which
+  // ITS matrix factorises with all pivots > 0 (5 = none does); the wavefront leaves the loop when every group has one.
+  int lv = 5;
+  bool done = false;
+  for (int level = 0; level < 5; ++level) {
+    const float jit = jitter_of_level(level);
+#pragma unroll
+    for (int k = 0; k < N; ++k) m[k] = valid ? m0[k] + (k == i ? jit : 0.0f) : (k == i ? 1.0f : 0.0f);
+    Chol c;
+    cholesky_rows(m, c, i);
+    if (level == 0 && g == 0 && !c.bad) {   // z_t of level 0 for the main launch
+      float epsL = eps[q * N + i];
+      float acc = mus[q * N + i];
+      dpp_guard(epsL);
+      lower_matvec_acc<0>(acc, c, epsL, i);
+      zst[q * N + i] = acc;
+    }
+    if (!done && !c.bad) lv = level, done = true;
+    if (!__any(!done)) break;
+  }
+  if (i == 0 && g == 0 && lv > 0) atomic_max_i32(levels + 0, lv);
+  if (i == 0 && g == 1 && lv > 0) atomic_max_i32(levels + 1, lv);
+}
+
+// ---- main: the four terms of step (b,t) and, with GRADS, every gradient of SUM(terms) (unit upstream) --------------
+template <bool GRADS, bool HAS_GQ>
+__device__ __forceinline__ void elbo_main(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps,
+                                          float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
+                                          const kvae_lgssm_input_grads &G, int b, int t, ELds &L) {
+  if (levels[0] != 0 || levels[1] != 0) return;   // jittered batch: the generic kernel computes this call
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, T = P.T;
+  const int64_t bT = (int64_t)b * T, q = bT + t;
+  const bool has_prev = t >= 1, has_next = t + 1 < T;
+  // ---- the four matrices, rows on lanes ----
+  const bool valid = g == 0 || (g == 1 && has_prev) || (g == 2 && has_next && GRADS) || (g == 3 && t == 0);
+  const float *X = Sigs + q * NN;
+  if (g == 1 && has_prev) X = stack_at(P.Q, b, t);
+  if (g == 2 && has_next) X = stack_at(P.Q, b, t + 1);
+  if (g == 3 && t == 0) X = P.Sigma0 + (int64_t)b * P.Sigma0_sb;
+  float m[N];
+  load_sym_rows(X, m, i, g == 3 ? 0.0f : 1e-6f, g == 3);   // level 0 of _safe_cholesky; Sigma0 as MultivariateNormal takes it
+  if (!valid) identity_rows(m, i);
+  Chol c;
+  cholesky_rows(m, c, i);
+  // ---- z, operands, residuals: wv (g0), d_t (g1), d_{t+1} (g2), z_0 - mu0 (g3) ----
+  const float zt = zst[q * N + i];
+  const float zp = has_prev ? zst[(q - 1) * N + i] : 0.0f, zn = has_next ? zst[(q + 1) * N + i] : 0.0f;
+  const int ts = g == 2 && has_next ? t + 1 : t;           // the step whose A, B, u this group multiplies
+  const float vecL = g == 2 ? zt : zp;
+  const float uL = P.U[(bT + ts) * N + i];
+  const float Az = matvec_rows(stack_at(P.A, b, ts), vecL, i);
+  const float Bu = matvec_rows(stack_at(P.Bm, b, ts), uL, i);
+  float rhs = zt - mus[q * N + i];
+  if (g == 1) rhs = zt - (Az + Bu);
+  if (g == 2) rhs = zn - (Az + Bu);
+  if (g == 3) rhs = zt - P.mu0[(int64_t)b * P.mu0_sb + i];
+  if (!valid) rhs = 0.0f;
+  // ---- L^{-1} rhs, quadratic forms, log-determinants ----
+  float y = rhs;
+  fsub_step<0>(c, y);
+  const float xf = y * c.rinv;
+  const float quad = row_sum(xf * xf), logdet = row_sum(__logf(c.ld));
+  // emission (p = 2): e = y - C z, R factorised without jitter
+  const float *C = stack_at(P.C, b, t);
+  const float Cl0 = C[i], Cl1 = C[N + i];
+  const float e0 = P.Y[q * 2] - row_sum(Cl0 * zt), e1 = P.Y[q * 2 + 1] - row_sum(Cl1 * zt);
+  const float l00 = __builtin_amdgcn_sqrtf(P.R[0]), l10 = P.R[2] / l00, l11 = __builtin_amdgcn_sqrtf(P.R[3] - l10 * l10);
+  const float w0 = e0 / l00, w1 = (e1 - l10 * w0) / l11;
+  const float qe1 = w1 / l11, qe0 = (w0 - l10 * qe1) / l00;      // R^{-1} e
+  const float mkr = *mask_addr(P, b, t);
+  const float mk = P.mask ? mkr : 1.0f;
+  const float gauss = -0.5f * (N * KV_LOG2PI + quad) - logdet;   // log N(rhs; 0, L L^T) of this group
+  if (i == 0) {
+    if (g == 0) {
+      terms[q * 4 + 3] = -gauss;                                 // entropy
+      terms[q * 4 + 1] = mk * (-0.5f * (2 * KV_LOG2PI + (w0 * w0 + w1 * w1)) - (__logf(l00) + __logf(l11)));
+    }
+    if (g == 1) terms[q * 4 + 0] = has_prev ? gauss : 0.0f;      // transition
+    if (g == 3) terms[q * 4 + 2] = t == 0 ? gauss : 0.0f;        // init
+  }
+  if constexpr (GRADS) {
+    // ---- (L L^T)^{-1} rhs in every group: v_t (g1), v_{t+1} (g2), Sigma0^{-1}(z0 - mu0) (g3) ----
+    float v = xf * c.rinv;
+    bsub_step<N - 1>(c, v, i);
+    const float vtL = has_prev ? __shfl(v, 16 + i, 64) : 0.0f;   // L-layout copies in every group
+    const float viL = t == 0 ? __shfl(v, 48 + i, 64) : 0.0f;
+    f4 vtW, vnW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vtW[r] = has_prev ? __shfl(v, 16 + 4 * g + r, 64) : 0.0f;
+      vnW[r] = has_next ? __shfl(v, 32 + 4 * g + r, 64) : 0.0f;
+    }
+    // gz_t = -v_t + A_{t+1}^T v_{t+1} + mask C^T R^{-1} e - Sigma0^{-1}(z_0 - mu0)
+    const f4 AnC = load_c(stack_at(P.A, b, has_next ? t + 1 : t), i, g);
+    const float gz = -vtL + mtv(AnC, vnW) + mk * (Cl0 * qe0 + Cl1 * qe1) - viL;
+    g_mus[q * N + i] = gz;
+    // input gradients of step t
+    float *gC = gstack_at(G.gC, b, t);
+    gC[i] = mk * qe0 * zt, gC[N + i] = mk * qe1 * zt;
+    G.gY[q * 2 + (i & 1)] = -mk * ((i & 1) ? qe1 : qe0);
+    const f4 zpW = has_prev ? load_w(zst + (q - 1) * N, g) : zero4();
+    store_rows(gstack_at(G.gA, b, t), vtL * zpW, i, g);          // gA_t = v_t z_{t-1}^T (row i, columns 4g..4g+3)
+    store_rows(gstack_at(G.gB, b, t), vtL * load_w(P.U + q * N, g), i, g);
+    if (G.gU) G.gU[q * N + i] = mtv(load_c(stack_at(P.Bm, b, t), i, g), vtW);   // B_t^T v_t
+    // ---- Cholesky backward into Sigma_s: sym(L^{-T} Phi L^{-1}), Phi = strict_tril(a eps^T) + diag((a eps + 1)/2), a = L^T gz
+    __syncthreads();
+    rows_to_tile(c.l, L.t[g], i);
+    __syncthreads();
+    const f4 Lc = tile_c(L.t[0], i, g);                          // C-layout of L_s
+    const float aL = mtv(Lc, l2w(gz, lane));
+    float xr[N];
+    inverse_rows(c, xr, i);                                      // L^{-1} of every group
+    __syncthreads();
+    rows_to_tile(xr, L.t[g], i);
+    __syncthreads();
+    const f4 Xs = tile_c(L.t[0], i, g);
+    const f4 epsW = load_w(eps + q * N, g);
+    const float epsL = eps[q * N + i];
+    f4 Pht;                                                      // C-layout of Phi^T: [4g+r][i] = Phi[i][4g+r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = 4 * g + r;
+      Pht[r] = col < i ? aL * epsW[r] : (col == i ? 0.5f * (aL * epsL + 1.0f) : 0.0f);
+    }
+    const f4 PX = mtn(Pht, Xs);                                  // Phi L^{-1}
+    const f4 S = mtn(Xs, PX);                                    // L^{-T} Phi L^{-1}
+    store_rows(g_Sigs + q * NN, symmetrise(S, L.s, i, g), i, g);
+    if constexpr (HAS_GQ) {   // gQ_t = 1/2 v v^T - 1/2 (L_Q L_Q^T)^{-1}
+      const f4 Xq = tile_c(L.t[1], i, g);
+      const f4 Qi = mtn(Xq, Xq);
+      const f4 gq = has_prev ? 0.5f * (vtW * vtL - Qi) : zero4();
+      store_c(gstack_at(G.gQ, b, t), gq, i, g);
+    }
+  }
+}
+
+}  // namespace n16
+}  // namespace kvae
+#endif
