@@ -147,8 +147,8 @@ int kvae_lgssm_alpha_lstm_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_s
  * If `g` / g_mus / g_Sigmas are non-NULL the gradients of SUM(terms) w.r.t. mus_smooth,
  * Sigmas_smooth and the problem inputs are written as well (unit upstream; the caller scales).
  * eps: [B,T,n] standard normal draws. chol_levels: 2 ints of device scratch (zeroed by the call).
- * ws_lz: optional scratch [B,T,n*n+n]: the probe launch parks its level-0 factor and sample there so that the main
- * launch does not re-factorise neighbouring steps (NULL = always recompute). */
+ * ws_lz: optional scratch [B,T,n]: the probe launch parks its level-0 sample z_t there so that the main launch does not
+ * re-factorise the neighbouring steps (NULL = always recompute). */
 int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth,
                     const float *eps, float *terms, int32_t *chol_levels, float *ws_lz, float *g_mus,
                     float *g_Sigmas, const kvae_lgssm_input_grads *g, void *stream);

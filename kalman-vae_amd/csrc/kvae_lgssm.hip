@@ -163,6 +163,7 @@ static int check_problem(const kvae_lgssm_problem *p) {
   } while (0)
 
 // kvae_lgssm_wide.hip: the same bodies with 256 threads per sequence (used when n > 8)
+#define KVAE_N4_TPP_FWD_MIN_B 8192   /* measured crossover (tools/n4_sweep.sh): 4096 -> 190 vs 216 us, 32768 -> 1125 vs 673 us */
 #define KVAE_ELBO_TPP_MIN_STEPS 0   /* thread-per-step wins at every size measured (12.8k .. 1.6M steps), DESIGN.md */
 extern "C" void kvae_tpp_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
                                            float *ws, int32_t *levels, hipStream_t s);
@@ -176,6 +177,13 @@ extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init
                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
                                           float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
                                           hipStream_t s);
+extern "C" void kvae_tpp_launch_smooth_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
+                                              hipStream_t s);
+// from this many sequences on, n = 4 runs one THREAD per sequence (kvae_lgssm_tpp.hip) instead of one wavefront
+static int n4_tpp_min_b(const char *which, int dflt) {
+  const char *e = getenv(which);
+  return e ? atoi(e) : dflt;
+}
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s);
 // kvae_lgssm_n16.hip: (n, m, p) = (16, 16, 2) on the f32 matrix cores
@@ -221,6 +229,11 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
   if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && (st->aux || !do_filter)) {
+    static const int tpp_b = n4_tpp_min_b("KVAE_N4_TPP_FWD_MIN_B", KVAE_N4_TPP_FWD_MIN_B);
+    if (prob->B >= tpp_b) {
+      kvae_tpp_launch_smooth_fwd_n4(prob, st, do_filter, do_rts, s);
+      return launch_status("k_smooth_fwd_n4_tpp");
+    }
     // rts-only calls need no gains; filter calls use the fused-phase kernel when the caller provides aux
     k_smooth_fwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts);
     return launch_status("k_smooth_fwd_n4");

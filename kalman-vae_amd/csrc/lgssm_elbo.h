@@ -74,9 +74,10 @@ KV_DEV void atomic_max_i32(int32_t *p, int32_t v) { if (v > *p) *p = v; }
 KV_DEV void atomic_max_i32(int32_t *p, int32_t v) { atomicMax(p, v); }
 #endif
 
-// ws (optional) receives per (b,t) the level-0 factor L_t (n*n) and the sample z_t = mu_t + L_t eps_t (n): when the
-// whole batch resolves to level 0 — the normal case — the main kernel reads them instead of re-factorising the
-// two neighbouring steps (3x fewer Cholesky factorisations and no re-reads of Sigma_s[t-1], Sigma_s[t+1]).
+// ws (optional) receives per (b,t) the sample z_t = mu_t + L_t eps_t (n floats) of level 0: when the whole batch resolves to
+// level 0 — the normal case — the main kernel reads z_{t-1}, z_{t+1} from it instead of re-factorising the two neighbouring
+// steps (no re-reads of Sigma_s[t-1], Sigma_s[t+1]; its own factor it recomputes, which is cheaper than the 4 n^2 bytes each
+// way that parking it would cost: HBM traffic of the pair of launches stays within ~1.1x of the algorithmic bytes).
 template <class D>
 KV_DEV void elbo_probe_body(const D d, const kvae_lgssm_problem &P, const float *Sig_s, const float *mus,
                             const float *eps, float *ws, int32_t *levels, int b, int t, ElboLds<D> &L) {
@@ -87,12 +88,11 @@ KV_DEV void elbo_probe_body(const D d, const kvae_lgssm_problem &P, const float 
     copy_in(L.eps, eps + q0 * n, n);
     copy_in(L.mu, mus + q0 * n, n);
     KV_SYNC();
-    float *w = ws + q0 * (nn + n);
-    KV_PAR(e, nn) { w[e] = L.Ls[e]; }
+    float *w = ws + q0 * n;
     KV_PAR(i, n) {
       float acc = L.mu[i];
       for (int k = 0; k <= i; ++k) acc = fmaf(L.Ls[i * n + k], L.eps[k], acc);
-      w[nn + i] = acc;
+      w[i] = acc;
     }
     KV_SYNC();
   }
@@ -141,12 +141,12 @@ KV_DEV void elbo_body(const D d, const kvae_lgssm_problem &P, const float *mus, 
   const bool has_prev = t >= 1, has_next = t + 1 < T;
 
   // ---- z_{t-1}, z_t, z_{t+1} = mu_s + chol(Sigma_s) eps  (kalman_filter.py:348-351) ----------
-  const bool stashed = (ws != nullptr) && lvS == 0;   // the probe launch already factorised every step at level 0
+  const bool stashed = (ws != nullptr) && lvS == 0;   // the probe launch already sampled every step at level 0
   if (stashed) {
-    copy_in(L.Ls, ws + q * (nn + n), nn);
+    safe_chol_at_level(L.Ls, L.sym, Sigs + q * nn, n, 0);
     for (int dt = -1; dt <= 1; ++dt) {
       const int tt = t + dt;
-      if (tt >= 0 && tt < T) copy_in(L.z[dt + 1], ws + (bT + tt) * (nn + n) + nn, n);
+      if (tt >= 0 && tt < T) copy_in(L.z[dt + 1], ws + (bT + tt) * n, n);
     }
     KV_SYNC();
   }

@@ -202,15 +202,20 @@ __global__ __launch_bounds__(1024) void k_loss_head_fwd(const float *__restrict_
   __shared__ float red[3][1024];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   const int64_t n4 = ((n & 3) == 0 && ((((uintptr_t)lpx | (uintptr_t)regf | (uintptr_t)mask) & 15) == 0)) ? n / 4 : 0;
+  // mask == NULL means "every frame observed".  Loads are always issued from a VALID address (lpx stands in) and the value
+  // selected afterwards: hipcc may hoist a load out of a short `mask ? mask[i] : 1` block (see mask_addr() in lgssm_fwd.h).
+  const float *msrc = mask ? mask : lpx;
   for (int64_t i = threadIdx.x; i < n4; i += 1024) {
     const float4 a = reinterpret_cast<const float4 *>(lpx)[i], b = reinterpret_cast<const float4 *>(regf)[i];
-    const float4 m = mask ? reinterpret_cast<const float4 *>(mask)[i] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 mr = reinterpret_cast<const float4 *>(msrc)[i];
+    const float4 m = mask ? mr : make_float4(1.f, 1.f, 1.f, 1.f);
     s0 += (a.x * m.x + a.y * m.y) + (a.z * m.z + a.w * m.w);
     s1 += (b.x * m.x + b.y * m.y) + (b.z * m.z + b.w * m.w);
     s2 += (m.x + m.y) + (m.z + m.w);
   }
   for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) {
-    const float mk = mask ? mask[i] : 1.f;
+    const float mraw = msrc[i];
+    const float mk = mask ? mraw : 1.f;
     s0 = fmaf(lpx[i], mk, s0);
     s1 = fmaf(regf[i], mk, s1);
     s2 += mk;
@@ -239,8 +244,10 @@ __global__ __launch_bounds__(256) void k_loss_head_bwd(const float *__restrict__
                                                        const float *__restrict__ mask, float kf_w, float *__restrict__ g_lpx,
                                                        float *__restrict__ g_regf, float *__restrict__ g_kf, int64_t n) {
   const float gg = g[0], c0 = gg * coef[0], c1 = gg * coef[1];
+  const float *msrc = mask ? mask : g_lpx;   // always a valid address, value selected afterwards (see k_loss_head_fwd)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float mk = mask ? mask[i] : 1.f;
+    const float mraw = msrc[i];
+    const float mk = mask ? mraw : 1.f;
     g_lpx[i] = c0 * mk;
     g_regf[i] = c1 * mk;
   }

@@ -2,8 +2,11 @@
 
 Same constructor, parameters and state_dict keys as the reference's DynamicsParameter
 (kvae/kalman/dyn_param.py:5-63): A[K,n,n], B[K,n,m], C[K,p,n], lstm.*, head_w.*.
-The recurrent net itself runs on PyTorch-ROCm (MIOpen RNN); the mixing A_t = sum_k alpha_tk A_k
-(dyn_param.py:58-60) is the HIP `kvae_mix_fwd/bwd` kernel and yields one packed step record.
+On a HIP device the recurrence is hand-written HIP: `kvae_lstm_fwd/bwd` for a fully observed sequence (the whole T loop
+in one launch; the three weight gradients are small rocBLAS GEMMs on its d_pre output) and, when a mask is given, the
+cell runs INSIDE the filter kernel (`kvae_lgssm_filter_alpha_lstm` / `kvae_lgssm_alpha_lstm_bwd`, kalman_filter.py here).
+The mixing A_t = sum_k alpha_tk A_k (dyn_param.py:58-60) is `kvae_mix_fwd/bwd` and yields one packed step record.
+Hidden sizes above 52 fall back to nn.LSTM (MIOpen), which cannot be captured into a hipGraph.
 """
 import torch
 import torch.nn as nn

@@ -1,8 +1,10 @@
 """torch.autograd bridge to the HIP LGSSM kernels (C ABI: include/kvae_lgssm.h).
 
 PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd graph.
-Every numerical step of filter / RTS smoother / ELBO / mixing — forward and backward — runs in
-libkvae_lgssm.so.  Nothing in this file computes on the host or falls back to aten ops.
+Every numerical step of filter / RTS smoother / ELBO / mixing / recurrences — forward and backward — runs in
+libkvae_lgssm.so, with two exceptions that stay torch ops on the same stream: the weight gradients of the LSTM / bi-GRU
+/ head are plain GEMMs (rocBLAS) over the d_pre / g_logit tensors the BPTT kernels write, and trivial reductions
+(`terms.sum`).  Nothing computes on the host.
 
 Per-step operands (A_t, B_t, C_t, Q_t) reach the kernels as strided "stacks": either slots of ONE
 packed record tensor [B,T,E] produced by `mix_dynamics` (mixture-of-K case: a single launch writes
@@ -207,7 +209,7 @@ class LgssmElbo(torch.autograd.Function):
         Sigs_c, eps_c = _f32c(Sigs), _f32c(eps)
         terms = torch.empty(Bsz, T, 4, device=dev, dtype=torch.float32)
         levels = torch.empty(2, device=dev, dtype=torch.int32)
-        ws_lz = torch.empty(Bsz, T, n * n + n, device=dev, dtype=torch.float32)
+        ws_lz = torch.empty(Bsz, T, n, device=dev, dtype=torch.float32)   # z_t parked by the probe launch
         want = any(ctx.needs_input_grad)
         g_mus = g_Sigs = sink = None
         if want:

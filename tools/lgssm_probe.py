@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Timing (HIP events) and a C-oracle check of the n = 16 LGSSM kernels through the op layer, at the BASELINE configs[4]
-shard (B = 512, T = 200) by default:  filter only, RTS only, filter + RTS, ELBO, backward.
-  python3 tools/n16_probe.py [--B 512] [--T 200] [--iters 10] [--q-per-step] [--check]
-KVAE_N16=0 selects the generic kernels for A/B runs."""
+"""Timing (HIP events) and a C-oracle check of the LGSSM kernels through the op layer - filter only, RTS only, filter + RTS,
+ELBO, backward - with the algorithmic GB/s of SURVEY.md section 8(d) next to each.  Defaults: the BASELINE configs[4] shard.
+  python3 tools/lgssm_probe.py [--n 16] [--B 512] [--T 200] [--iters 10] [--q-per-step] [--mask] [--check]
+A/B switches (read once per process): KVAE_N16=0 generic kernels for n = 16; KVAE_N4_TPP_FWD_MIN_B = number
+of sequences from which the n = 4 forward runs one thread per sequence."""
 import argparse
 import sys
 from pathlib import Path
@@ -15,6 +16,7 @@ from kvae.kalman import lgssm_ops as ops  # noqa: E402
 from kvae.kalman.lgssm_ops import LgssmElbo, LgssmSmooth, Slots, mix_dynamics  # noqa: E402
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=16)
 ap.add_argument("--B", type=int, default=512)
 ap.add_argument("--T", type=int, default=200)
 ap.add_argument("--iters", type=int, default=10)
@@ -23,7 +25,7 @@ ap.add_argument("--check", action="store_true", help="compare with the C oracle 
 ap.add_argument("--mask", action="store_true")
 a = ap.parse_args()
 dev = "cuda"
-B, T, n, m, p, K = a.B, a.T, 16, 16, 2, 3
+B, T, n, m, p, K = a.B, a.T, a.n, a.n, 2, 3
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).to(dev)
 A = (torch.eye(n).repeat(K, 1, 1) + 0.05 * torch.randn(K, n, n, generator=g)).to(dev).requires_grad_(True)
@@ -82,13 +84,18 @@ for _ in range(a.iters):
     (total / (B * T)).backward()
 prof = _native.profile_stop()
 us = {k: 1e3 * sorted(v)[len(v) // 2] for k, v in prof.items()}
-per = lambda t_us: f"{t_us:9.1f} us = {t_us / T * 1e3:7.0f} ns/step"
-print(f"n=16 B={B} T={T} q_per_step={a.q_per_step} mask={a.mask}")
+qs = 1 if a.q_per_step else 0
+by_fwd = 4 * (n * n * (1 + qs) + n * m + p * n + p + m + 1 + 3 * n + 3 * n * n)
+by_elbo = 4 * (2 * n + n * n + p + m + n * n + n * m + p * n + qs * n * n + 1)
+by_bwd = by_fwd + 4 * ((n + n * n) + n * n * (1 + qs) + n * m + p * n + p)
+per = lambda t_us, by=None: f"{t_us:9.1f} us = {t_us / T * 1e3:7.0f} ns/step" + (
+    f" = {by * B * T / (t_us * 1e-6) / 1e9:7.1f} GB/s algorithmic" if by and t_us > 0 else "")
+print(f"n={n} B={B} T={T} q_per_step={a.q_per_step} mask={a.mask}")
 print(f"  filter only   {per(t_filter)}")
 print(f"  rts only      {per(t_rts)}")
-print(f"  filter + rts  {per(t_smooth)}   (with grads/aux: {per(us.get('smooth_fwd', 0.0))})")
-print(f"  elbo          {per(t_elbo)}   (with grads: {per(us.get('elbo', 0.0))})")
-print(f"  backward      {per(us.get('smooth_bwd', 0.0))}")
+print(f"  filter + rts  {per(t_smooth, by_fwd)}   (with grads/aux: {per(us.get('smooth_fwd', 0.0))})")
+print(f"  elbo          {per(t_elbo, by_elbo)}   (with grads: {per(us.get('elbo', 0.0))})")
+print(f"  backward      {per(us.get('smooth_bwd', 0.0), by_bwd)}")
 
 if a.check:
     from golden_util import rel_err
