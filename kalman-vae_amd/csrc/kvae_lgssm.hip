@@ -111,6 +111,32 @@ __global__ __launch_bounds__(256) void k_mix_bwd_alpha(const float *base, const 
   if (idx < total) mix_bwd_alpha_elem(base, g_out, g_alpha, idx, K, E, accumulate);
 }
 
+// Wide records (E >= 128, i.e. n = 16: E = 544 / 768): one wavefront per row, lanes stride over E with coalesced reads of
+// g_out and base, K running sums per lane, butterfly reduction.  The thread-per-(row,k) kernel above walks E serially from
+// every thread (fine for E = 40, 6 us at configs[1]; 528 us at the configs[4] shard, where this one takes ~60).
+template <int KC>
+__global__ __launch_bounds__(256) void k_mix_bwd_alpha_wide(const float *__restrict__ base, const float *__restrict__ g_out,
+                                                            float *__restrict__ g_alpha, int64_t rows, int K, int E, int accumulate) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float acc[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) acc[k] = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    const float g = g_out[r * E + e];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+      if (k < K) acc[k] = fmaf(g, base[k * E + e], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    float v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0 && k < K) g_alpha[r * K + k] = accumulate ? g_alpha[r * K + k] + v : v;
+  }
+}
+
 __global__ void k_mix_bwd_partial(const float *alpha, const float *g_out, float *partials, int64_t rows, int K, int E) {
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e < E) mix_bwd_partial_elem(alpha, g_out, partials, blockIdx.x, e, rows, K, E);
@@ -400,8 +426,14 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
   if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int64_t ta = rows * K;
-  hipLaunchKernelGGL(k_mix_bwd_alpha, dim3((unsigned)((ta + 255) / 256)), dim3(256), 0, s, base, g_out, g_alpha, ta, K, E,
-                     accumulate_alpha);
+  if (E >= 128 && K <= 4)
+    k_mix_bwd_alpha_wide<4><<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(base, g_out, g_alpha, rows, K, E, accumulate_alpha);
+  else if (E >= 128)
+    k_mix_bwd_alpha_wide<KVAE_MAX_K><<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(base, g_out, g_alpha, rows, K, E,
+                                                                                        accumulate_alpha);
+  else
+    hipLaunchKernelGGL(k_mix_bwd_alpha, dim3((unsigned)((ta + 255) / 256)), dim3(256), 0, s, base, g_out, g_alpha, ta, K, E,
+                       accumulate_alpha);
   const int64_t nblk = kvae_mix_bwd_partials(rows);
   const int tpb = E >= 256 ? 256 : ((E + 63) / 64) * 64;
   hipLaunchKernelGGL(k_mix_bwd_partial, dim3((unsigned)nblk, (unsigned)((E + tpb - 1) / tpb)), dim3(tpb), 0, s, alpha, g_out,
