@@ -91,6 +91,50 @@ def n16_generic_fallback(DEV):
         assert rel_err(a.cpu(), b.cpu()) < 2e-4
 
 
+def n16_indefinite_q(DEV):
+    """(16,16,2) with a process noise that is NOT positive semi-definite (the reference's stability recipe does this at
+    n = 4): predicted covariances go indefinite, the natural-order elimination of the smoother gain meets a non-positive
+    pivot and the kernels must fall back to the partially pivoted one (getrf's pivot sequence, which is what the C
+    oracle's LU and torch.linalg.solve do).  Values vs the C oracle, gradients vs the torch oracle."""
+    from kvae.kalman.lgssm_ops import LgssmSmooth, Slots
+    from oracle import c_oracle
+    from oracle import torch_oracle as O
+    B, T, n, m, p = 3, 12, 16, 16, 2
+    g = torch.Generator().manual_seed(77)
+    A = 0.6 * torch.eye(n) + 0.15 * torch.randn(n, n, generator=g)
+    Bm = 0.1 * torch.randn(n, m, generator=g)
+    Cm = 0.3 * torch.randn(p, n, generator=g)
+    Qh = 0.3 * torch.randn(n, n, generator=g)
+    Q = 0.5 * (Qh + Qh.T)                                   # symmetric, indefinite
+    assert float(torch.linalg.eigvalsh(Q).min()) < -0.1
+    Y, U = torch.randn(B, T, p, generator=g), 0.3 * torch.randn(B, T, m, generator=g)
+    R, mu0, S0 = 0.03 * torch.eye(p), torch.zeros(n), 0.5 * torch.eye(n)
+    dev = lambda t: t.to(DEV)
+    leaves = [dev(t).clone().requires_grad_(True) for t in (A, Bm, Cm, Y)]
+    outs = LgssmSmooth.apply(leaves[3], dev(U), None, None, leaves[0], leaves[1], leaves[2], dev(Q), dev(R), dev(mu0), dev(S0),
+                             Slots(), True)
+    ref = c_oracle.smooth(Y, U, None, A, Bm, Cm, Q, R, mu0, S0)
+    assert float(torch.linalg.eigvalsh(0.5 * (ref["Sigmas_pred"][0, -1] + ref["Sigmas_pred"][0, -1].T)).min()) < 0   # really indefinite
+    for k, v in zip(("mus_smooth", "Sigmas_smooth", "mus_filt", "Sigmas_filt", "mus_pred", "Sigmas_pred"), outs):
+        assert rel_err(v.detach().cpu(), ref[k]) < 2e-3, k
+    w = [torch.randn(o.shape, generator=g) for o in outs[:2]]
+    (sum((o * dev(wi)).sum() for o, wi in zip(outs[:2], w))).backward()
+    cl = [t.clone().requires_grad_(True) for t in (A, Bm, Cm, Y)]
+    mu, Sig = mu0.expand(B, -1).unsqueeze(-1), S0.expand(B, -1, -1)
+    ex = lambda M: M.expand(B, -1, -1)
+    mfs, Sfs, mps, Sps = [], [], [], []
+    for t in range(T):
+        mu, Sig, mu_p, Sig_p = O.filter_step(mu, Sig, cl[3][:, t], U[:, t], ex(cl[0]), ex(cl[1]), ex(cl[2]), Q, R, torch.ones(B))
+        mfs.append(mu), Sfs.append(Sig), mps.append(mu_p), Sps.append(Sig_p)
+    mus, Sigs = [mfs[-1]], [Sfs[-1]]
+    for t in range(T - 2, -1, -1):
+        m_s, S_s = O.smooth_step(Sfs[t], Sps[t + 1], Sigs[0], mfs[t], mps[t + 1], mus[0], ex(cl[0]))
+        mus.insert(0, m_s), Sigs.insert(0, S_s)
+    ((torch.stack(mus, 1).squeeze(-1) * w[0]).sum() + (torch.stack(Sigs, 1) * w[1]).sum()).backward()
+    for name, got, want in zip("A B C Y".split(), leaves, cl):
+        assert rel_err(got.grad.cpu(), want.grad) < 1e-2, name
+
+
 def linearity(DEV, B=256, T=50):
     """Size-independent property at configs[1] size: the smoothed MEANS are linear in (y, u, mu0) for fixed
     dynamics, and the covariances do not depend on y at all."""
@@ -107,12 +151,13 @@ def linearity(DEV, B=256, T=50):
 
 
 
-def safe_cholesky_levels(DEV):
+def safe_cholesky_levels(DEV, n=4):
     """_safe_cholesky semantics: one bad Q_t forces the WHOLE batch up the jitter ladder / to the diagonal
-    fallback, exactly like the oracle (kalman_filter.py:282-302)."""
+    fallback, exactly like the oracle (kalman_filter.py:282-302).  n = 16: the matrix-core ELBO kernels resolve the
+    level in their probe and hand levels > 0 to the generic main kernel on the device."""
     from kvae.kalman.lgssm_ops import LgssmElbo, Slots
     from oracle import c_oracle
-    B, T, n, m, p = 2, 4, 4, 4, 2
+    B, T, m, p = 2, 4, n, 2
     A, Bm, Cm, alpha, Y, U, mask, eps = _random_problem(B, T, n, m, p, 1, 5, DEV)
     R = 0.03 * torch.eye(p, device=DEV)
     mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)

@@ -120,12 +120,17 @@ def test_n16_generic_fallback():
     parity_cases.n16_generic_fallback(DEV)
 
 
+def test_n16_indefinite_q_takes_the_pivoted_solve():
+    parity_cases.n16_indefinite_q(DEV)
+
+
 def test_linearity_full_size():
     parity_cases.linearity(DEV, 256, 50)
 
 
-def test_safe_cholesky_levels():
-    parity_cases.safe_cholesky_levels(DEV)
+@pytest.mark.parametrize("n", [4, 16])
+def test_safe_cholesky_levels(n):
+    parity_cases.safe_cholesky_levels(DEV, n)
 
 
 @pytest.mark.parametrize("name,levels", JITTER_CASES)
