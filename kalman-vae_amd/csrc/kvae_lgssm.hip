@@ -189,7 +189,6 @@ static int check_problem(const kvae_lgssm_problem *p) {
   } while (0)
 
 // kvae_lgssm_wide.hip: the same bodies with 256 threads per sequence (used when n > 8)
-#define KVAE_N4_TPP_FWD_MIN_B 8192   /* measured crossover (tools/n4_sweep.sh): 4096 -> 190 vs 216 us, 32768 -> 1125 vs 673 us */
 #define KVAE_ELBO_TPP_MIN_STEPS 0   /* thread-per-step wins at every size measured (12.8k .. 1.6M steps), DESIGN.md */
 extern "C" void kvae_tpp_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
                                            float *ws, int32_t *levels, hipStream_t s);
@@ -203,13 +202,6 @@ extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init
                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
                                           float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
                                           hipStream_t s);
-extern "C" void kvae_tpp_launch_smooth_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
-                                              hipStream_t s);
-// from this many sequences on, n = 4 runs one THREAD per sequence (kvae_lgssm_tpp.hip) instead of one wavefront
-static int n4_tpp_min_b(const char *which, int dflt) {
-  const char *e = getenv(which);
-  return e ? atoi(e) : dflt;
-}
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s);
 // kvae_lgssm_n16.hip: (n, m, p) = (16, 16, 2) on the f32 matrix cores
@@ -221,12 +213,22 @@ extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const fl
 extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
                                      float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
                                      const kvae_lgssm_input_grads *g, int have_g, hipStream_t s);
+// kvae_lgssm_n16.hip (lgssm_q4.h): (n, m, p) = (4, 4, 2), sixteen sequences per wavefront
+extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
+                                   hipStream_t s);
+extern "C" void kvae_q4_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                                   const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s);
 extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                                     const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s);
 
 // The n = 16 kernels move matrices with 16-byte accesses: every per-step operand must start on a 16-byte boundary.
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static bool stack16(const kvae_stack &s) { return aligned16(s.ptr) && s.sb % 4 == 0 && s.st % 4 == 0; }
+static bool q4_ok(const kvae_lgssm_problem *p) {
+  static const int env = getenv("KVAE_Q4") ? atoi(getenv("KVAE_Q4")) : 1;   // 0: one wavefront per sequence (A/B runs)
+  return env && p->n == 4 && p->m == 4 && p->p == 2 && stack16(p->A) && stack16(p->Bm) && stack16(p->Q) &&
+         aligned16(p->Sigma0) && p->Sigma0_sb % 4 == 0 && (reinterpret_cast<uintptr_t>(p->Y) & 7u) == 0;
+}
 static bool n16_ok(const kvae_lgssm_problem *p) {
   static const int env = getenv("KVAE_N16") ? atoi(getenv("KVAE_N16")) : 1;   // 0: generic kernels (A/B runs)
   return env && p->n == 16 && p->m == 16 && p->p == 2 && stack16(p->A) && stack16(p->Bm) && stack16(p->C) && stack16(p->Q) &&
@@ -254,12 +256,12 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
   if (!st || !st->mus_filt || !st->Sigmas_filt || !st->mus_pred || !st->Sigmas_pred) return KVAE_ERR_NULL;
   if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
+  if (q4_ok(prob) && aligned16(st->Sigmas_filt) && aligned16(st->Sigmas_pred) && aligned16(st->Sigmas_smooth) &&
+      aligned16(st->aux)) {
+    kvae_q4_launch_fwd(prob, st, do_filter, do_rts, s);
+    return launch_status("k_smooth_fwd_q4");
+  }
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && (st->aux || !do_filter)) {
-    static const int tpp_b = n4_tpp_min_b("KVAE_N4_TPP_FWD_MIN_B", KVAE_N4_TPP_FWD_MIN_B);
-    if (prob->B >= tpp_b) {
-      kvae_tpp_launch_smooth_fwd_n4(prob, st, do_filter, do_rts, s);
-      return launch_status("k_smooth_fwd_n4_tpp");
-    }
     // rts-only calls need no gains; filter calls use the fused-phase kernel when the caller provides aux
     k_smooth_fwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts);
     return launch_status("k_smooth_fwd_n4");
@@ -334,6 +336,17 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (with_rts && (!saved->mus_smooth || !saved->Sigmas_smooth)) return KVAE_ERR_NULL;
   if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
+  if (with_rts && saved->aux && q4_ok(prob)) {   // sixteen sequences per wavefront (lgssm_q4.h)
+    const int fp = (up->mus_filt != nullptr) + (up->Sigmas_filt != nullptr) + (up->mus_pred != nullptr) + (up->Sigmas_pred != nullptr);
+    const auto gs16 = [](const kvae_gstack &g) { return !g.ptr || (aligned16(g.ptr) && g.sb % 4 == 0 && g.st % 4 == 0); };
+    const bool al = aligned16(saved->Sigmas_filt) && aligned16(saved->Sigmas_pred) && aligned16(saved->Sigmas_smooth) &&
+                    aligned16(saved->aux) && aligned16(ws) && aligned16(up->Sigmas_smooth) && aligned16(up->Sigmas_filt) &&
+                    aligned16(up->Sigmas_pred) && gs16(out->gA) && gs16(out->gB) && gs16(out->gQ) && aligned16(out->g_Sigma0);
+    if (up->mus_smooth && up->Sigmas_smooth && (fp == 0 || fp == 4) && al && out->gU) {
+      kvae_q4_launch_bwd(prob, saved, up, out, ws, fp == 4, s);
+      return launch_status("k_smooth_bwd_q4");
+    }
+  }
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {
     k_smooth_bwd_n4<SDims<4, 4, 2>><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws, with_rts);
     return launch_status("k_smooth_bwd_n4");

@@ -10,7 +10,6 @@
 #include <hip/hip_runtime.h>
 
 #include "lgssm_elbo.h"
-#include "lgssm_n4.h"
 #include "regime.h"
 
 using namespace kvae;
@@ -102,26 +101,4 @@ extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init
 #undef X
     default: return 0;
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Filter + RTS smoother for n = m = 4, p = 2 with one THREAD per sequence (lgssm_n4.h bodies, every tile in registers,
-// no LDS, no cross-lane traffic): 64 sequences per wavefront.  One wavefront per sequence keeps at most 16 of 64 lanes busy,
-// which is the right trade at BASELINE configs[1] (256 sequences: latency is all that matters: 128 vs 202 us) but leaves the
-// chip under-used once there are more sequences than wave slots (B = 32768: 1125 vs 673 us = 0.62 vs 1.04 TB/s algorithmic);
-// kvae_lgssm.hip switches to this kernel from KVAE_N4_TPP_FWD_MIN_B sequences on.  The adjoint built the same way spills
-// (256 VGPR + 134 AGPR + scratch) and is 10x slower than one wavefront per sequence at every size: not instantiated.
-// ---------------------------------------------------------------------------------------------------------------
-template <class D>
-__global__ __launch_bounds__(64) void k_smooth_fwd_n4_tpp(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= P.B) return;
-  N4Lds<D::MMAX> L;
-  const D d(P.n, P.m, P.p);
-  if (do_filter) filter_sweep_n4(d, P, S, b, L);
-  if (do_rts) rts_sweep_n4(d, P, S, b, L);
-}
-extern "C" void kvae_tpp_launch_smooth_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
-                                              hipStream_t s) {
-  k_smooth_fwd_n4_tpp<SDims<4, 4, 2>><<<dim3((unsigned)((p->B + 63) / 64)), dim3(64), 0, s>>>(*p, *st, do_filter, do_rts);
 }

@@ -111,8 +111,8 @@ def test_train_step_gpu(name, kind):
                                          (5, 1, 16, 16, 2, 2), (8192, 6, 4, 4, 2, 3)])
 def test_vs_oracle_random(B, T, n, m, p, K):
     """Values vs the C oracle at every size, incl. the FULL BASELINE configs[4] shard (512, 200, 16); gradients vs the
-    torch oracle's autograd up to configs[1] size (256, 50, 4) and for n = 16 at (8, 200, 16).  (8192, 6, 4) is the
-    thread-per-sequence forward that n = 4 switches to from 8192 sequences on."""
+    torch oracle's autograd up to configs[1] size (256, 50, 4) and for n = 16 at (8, 200, 16).  (8192, 6, 4): many wavefronts of the sixteen-
+    sequences-per-wavefront n = 4 kernels, with a ragged last one in (7, 33, 4)."""
     parity_cases.vs_oracle_random(DEV, B, T, n, m, p, K)
 
 

@@ -9,9 +9,10 @@ lines = [l.strip() for l in open(sys.argv[1]) if l.strip() and not l.strip().sta
 ins = [l for l in lines if re.match(r"^(v_|s_|ds_|global_|buffer_|flat_|scratch_)", l)]
 bad = 0
 for i, l in enumerate(ins):
-    if not l.startswith("v_fmac_f32_dpp"):
+    m0 = re.match(r"v_(?:fmac|mul)_f32_dpp (v\d+), (v\d+),", l)
+    if not m0:
         continue
-    src = re.match(r"v_fmac_f32_dpp (v\d+), (v\d+),", l).group(2)
+    src = m0.group(2)
     waits = 0
     for k in range(i - 1, max(i - 4, -1), -1):
         p = ins[k]
@@ -28,5 +29,5 @@ for i, l in enumerate(ins):
                 print(f"HAZARD: '{p}' then '{l}' with {waits} wait state(s)")
                 bad += 1
         waits += 1
-print(f"checked {sum(1 for l in ins if l.startswith('v_fmac_f32_dpp'))} v_fmac_f32_dpp, {bad} hazard(s)")
+print(f"checked {sum(1 for l in ins if re.match(r'v_(fmac|mul)_f32_dpp', l))} hand-written DPP instructions, {bad} hazard(s)")
 sys.exit(1 if bad else 0)
