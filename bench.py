@@ -361,15 +361,16 @@ def main():
             ach = chain[dom]["GBps"]
             n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
             n16 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (16, 16, 2)
-            kname = {"smooth_fwd": "k_smooth_fwd_n4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
-                     "smooth_bwd": "k_smooth_bwd_n4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
+            kname = {"smooth_fwd": "k_smooth_fwd_q4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
+                     "smooth_bwd": "k_smooth_bwd_q4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
                      "elbo": "k_elbo_tpp(+probe)" if n4 else "k_elbo(+probe)"}[dom]
             roofline = {"kernel": kname,
                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom), "traffic_source": traffic_src,
                         "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["per_step_us"],
-                        "note": "T-deep dependent recursion, one sequence per wavefront: latency-bound, not byte-bound, "
-                                "whenever B is far below the ~8000 wave slots of the chip"}
+                        "note": "T-deep dependent recursion, " + ("sixteen sequences" if n4 else "one sequence") +
+                                " per wavefront: latency-bound, not byte-bound, whenever the batch is far below the "
+                                "wave slots of the chip (" + ("B/16" if n4 else "B") + " wavefronts here)"}
             # the kernel that dominates the STEP is outside the LGSSM path: the decoder 32->128 block on the f32 matrix cores
             up = chain.get("dec_up_fwd_s8")
             if up and (cfg.img_size, tuple(cfg.decoder_channels)) == (32, (32, 32, 32)):

@@ -62,42 +62,30 @@ __device__ __forceinline__ float qmax(float x) { x = fmaxf(x, qx1(x)); x = fmaxf
 __device__ __forceinline__ void guard(Mat &m) { asm volatile("s_nop 1" : "+v"(m.c[0]), "+v"(m.c[1]), "+v"(m.c[2]), "+v"(m.c[3])); }
 
 // ---- products: the DPP source is always the SECOND matrix / the vector; callers guard() it if their own VALU code made it --
+// (the four accumulators of a product are advanced round-robin: consecutive instructions are independent, so the wavefront -
+//  usually alone on its SIMD - issues them back to back instead of waiting out each FMA's latency)
 __device__ __forceinline__ Mat mul_nn(const Mat &A, const Mat &B) {     // A B
   Mat C;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    C.c[c] = mul_q<0>(B.c[c], A.c[0]);
-    fmac_q<1>(C.c[c], B.c[c], A.c[1]);
-    fmac_q<2>(C.c[c], B.c[c], A.c[2]);
-    fmac_q<3>(C.c[c], B.c[c], A.c[3]);
-  }
+  C.c[0] = mul_q<0>(B.c[0], A.c[0]), C.c[1] = mul_q<0>(B.c[1], A.c[0]), C.c[2] = mul_q<0>(B.c[2], A.c[0]), C.c[3] = mul_q<0>(B.c[3], A.c[0]);
+  fmac_q<1>(C.c[0], B.c[0], A.c[1]), fmac_q<1>(C.c[1], B.c[1], A.c[1]), fmac_q<1>(C.c[2], B.c[2], A.c[1]), fmac_q<1>(C.c[3], B.c[3], A.c[1]);
+  fmac_q<2>(C.c[0], B.c[0], A.c[2]), fmac_q<2>(C.c[1], B.c[1], A.c[2]), fmac_q<2>(C.c[2], B.c[2], A.c[2]), fmac_q<2>(C.c[3], B.c[3], A.c[2]);
+  fmac_q<3>(C.c[0], B.c[0], A.c[3]), fmac_q<3>(C.c[1], B.c[1], A.c[3]), fmac_q<3>(C.c[2], B.c[2], A.c[3]), fmac_q<3>(C.c[3], B.c[3], A.c[3]);
   return C;
 }
 __device__ __forceinline__ Mat mul_nn_acc(const Mat &A, const Mat &B, const Mat &C0) {     // A B + C0
   Mat C = C0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    fmac_q<0>(C.c[c], B.c[c], A.c[0]);
-    fmac_q<1>(C.c[c], B.c[c], A.c[1]);
-    fmac_q<2>(C.c[c], B.c[c], A.c[2]);
-    fmac_q<3>(C.c[c], B.c[c], A.c[3]);
-  }
+  fmac_q<0>(C.c[0], B.c[0], A.c[0]), fmac_q<0>(C.c[1], B.c[1], A.c[0]), fmac_q<0>(C.c[2], B.c[2], A.c[0]), fmac_q<0>(C.c[3], B.c[3], A.c[0]);
+  fmac_q<1>(C.c[0], B.c[0], A.c[1]), fmac_q<1>(C.c[1], B.c[1], A.c[1]), fmac_q<1>(C.c[2], B.c[2], A.c[1]), fmac_q<1>(C.c[3], B.c[3], A.c[1]);
+  fmac_q<2>(C.c[0], B.c[0], A.c[2]), fmac_q<2>(C.c[1], B.c[1], A.c[2]), fmac_q<2>(C.c[2], B.c[2], A.c[2]), fmac_q<2>(C.c[3], B.c[3], A.c[2]);
+  fmac_q<3>(C.c[0], B.c[0], A.c[3]), fmac_q<3>(C.c[1], B.c[1], A.c[3]), fmac_q<3>(C.c[2], B.c[2], A.c[3]), fmac_q<3>(C.c[3], B.c[3], A.c[3]);
   return C;
 }
-template <int C_>
-__device__ __forceinline__ float row_dot_lane(const Mat &A, const Mat &B, float acc) {   // acc + sum_k A_i[k] (lane C_'s B[k])
-  fmac_q<C_>(acc, B.c[0], A.c[0]);
-  fmac_q<C_>(acc, B.c[1], A.c[1]);
-  fmac_q<C_>(acc, B.c[2], A.c[2]);
-  fmac_q<C_>(acc, B.c[3], A.c[3]);
-  return acc;
-}
-__device__ __forceinline__ Mat mul_nt(const Mat &A, const Mat &B, const Mat &C0) {   // A B^T + C0
-  Mat C;
-  C.c[0] = row_dot_lane<0>(A, B, C0.c[0]);
-  C.c[1] = row_dot_lane<1>(A, B, C0.c[1]);
-  C.c[2] = row_dot_lane<2>(A, B, C0.c[2]);
-  C.c[3] = row_dot_lane<3>(A, B, C0.c[3]);
+__device__ __forceinline__ Mat mul_nt(const Mat &A, const Mat &B, const Mat &C0) {   // A B^T + C0 : C_i[c] += A_i[k] (lane c's B[k])
+  Mat C = C0;
+  fmac_q<0>(C.c[0], B.c[0], A.c[0]), fmac_q<1>(C.c[1], B.c[0], A.c[0]), fmac_q<2>(C.c[2], B.c[0], A.c[0]), fmac_q<3>(C.c[3], B.c[0], A.c[0]);
+  fmac_q<0>(C.c[0], B.c[1], A.c[1]), fmac_q<1>(C.c[1], B.c[1], A.c[1]), fmac_q<2>(C.c[2], B.c[1], A.c[1]), fmac_q<3>(C.c[3], B.c[1], A.c[1]);
+  fmac_q<0>(C.c[0], B.c[2], A.c[2]), fmac_q<1>(C.c[1], B.c[2], A.c[2]), fmac_q<2>(C.c[2], B.c[2], A.c[2]), fmac_q<3>(C.c[3], B.c[2], A.c[2]);
+  fmac_q<0>(C.c[0], B.c[3], A.c[3]), fmac_q<1>(C.c[1], B.c[3], A.c[3]), fmac_q<2>(C.c[2], B.c[3], A.c[3]), fmac_q<3>(C.c[3], B.c[3], A.c[3]);
   return C;
 }
 __device__ __forceinline__ float matvec(const Mat &A, float v, float acc) {          // acc + (A v)_i

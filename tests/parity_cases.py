@@ -72,11 +72,11 @@ def vs_oracle_random(DEV, B, T, n, m, p, K):
         assert rel_err(got.grad.cpu(), want.grad) < 3e-3, name
 
 
-def n16_generic_fallback(DEV):
-    """(16,16,2) operands that do NOT start on 16-byte boundaries take the run-time-dimension kernels instead of the
-    matrix-core ones (the latter move matrices with 16-byte accesses): same results either way."""
+def unaligned_fallback(DEV, n, m, p, B=3, T=9):
+    """Operands that do NOT start on 16-byte boundaries take the run-time-dimension kernels instead of the specialised
+    ones ((16,16,2): matrix cores; (4,4,2): sixteen sequences per wavefront - both move rows with 16-byte accesses):
+    same values and same gradients either way.  B = 19 at n = 4 also leaves the last wavefront's quads ragged."""
     from kvae.kalman.lgssm_ops import LgssmSmooth, Slots
-    B, T, n, m, p = 3, 9, 16, 16, 2
     A, Bm, Cm, alpha, Y, U, mask, _ = _random_problem(B, T, n, m, p, 1, 21, DEV)
     R, Q = 0.03 * torch.eye(p, device=DEV), 0.02 * torch.eye(n, device=DEV)
     mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)
@@ -84,11 +84,35 @@ def n16_generic_fallback(DEV):
     odd = torch.empty(B * T * n * n + 1, device=DEV)[1:].view(B, T, n, n)   # same values, 4 bytes off a 16-byte boundary
     odd.copy_(Astack)
     assert odd.data_ptr() % 16 != 0 and Astack.data_ptr() % 16 == 0
-    with torch.no_grad():
-        fast = LgssmSmooth.apply(Y, U, mask, None, Astack, Bm[0], Cm[0], Q, R, mu0, S0, Slots(), True)
-        slow = LgssmSmooth.apply(Y, U, mask, None, odd, Bm[0], Cm[0], Q, R, mu0, S0, Slots(), True)
+    res = []
+    for stack in (Astack, odd):
+        leaf = stack.clone().requires_grad_(True) if stack is Astack else None
+        if leaf is None:                      # .clone() would re-align it: take the gradient w.r.t. a view's base instead
+            base = torch.empty(B * T * n * n + 1, device=DEV)
+            base[1:].copy_(stack.reshape(-1))
+            base.requires_grad_(True)
+            leaf_in = base[1:].view(B, T, n, n)
+            assert leaf_in.data_ptr() % 16 != 0
+        else:
+            base, leaf_in = leaf, leaf
+        outs = LgssmSmooth.apply(Y, U, mask, None, leaf_in, Bm[0], Cm[0], Q, R, mu0, S0, Slots(), True)
+        gen = torch.Generator().manual_seed(5)
+        loss = sum((o * torch.randn(o.shape, generator=gen).to(DEV)).sum() for o in outs)
+        loss.backward()
+        gA = base.grad if base is leaf else base.grad[1:].view(B, T, n, n)
+        res.append(([o.detach().cpu() for o in outs], gA.cpu()))
+    (fast, gfast), (slow, gslow) = res
     for a, b in zip(fast, slow):
-        assert rel_err(a.cpu(), b.cpu()) < 2e-4
+        assert rel_err(a, b) < 2e-4
+    assert rel_err(gfast, gslow) < 5e-4
+
+
+def n16_generic_fallback(DEV):
+    unaligned_fallback(DEV, 16, 16, 2)
+
+
+def n4_generic_fallback(DEV):
+    unaligned_fallback(DEV, 4, 4, 2, B=19, T=11)
 
 
 def n16_indefinite_q(DEV):

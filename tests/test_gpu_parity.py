@@ -120,6 +120,10 @@ def test_n16_generic_fallback():
     parity_cases.n16_generic_fallback(DEV)
 
 
+def test_n4_generic_fallback():
+    parity_cases.n4_generic_fallback(DEV)
+
+
 def test_n16_indefinite_q_takes_the_pivoted_solve():
     parity_cases.n16_indefinite_q(DEV)
 
