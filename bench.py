@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-steady", action="store_true", help="skip the extra >= 2 s steady-state windows")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the eager event-timed pass (profiling runs: keeps the trace to the replayed graph's steps)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the LGSSM chain on the main stream")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher/rendezvous rehearsal on the CPU (gloo): no model, no GPU, marks the line dry_run")
@@ -131,6 +133,15 @@ def algorithmic_bytes(n, m, p, q_per_step):
     elbo = 4 * (2 * n + n * n + p + m + n * n + n * m + p * n + q * n * n + 1)
     bwd = fwd + 4 * ((n + n * n) + n * n * (1 + q) + n * m + p * n + p)
     return {"smooth_fwd": fwd, "elbo": elbo, "smooth_bwd": bwd}
+
+
+def elbo_grad_output_bytes(n, m, p, q_per_step):
+    """The training-mode ELBO launch also WRITES the gradient of the four terms (g_mus, g_Sigmas, gA, gB, gC, gy and, with a
+    per-step Q, gQ) next to the SURVEY's forward reads; the smoother backward then takes g_mus / g_Sigmas as its upstream.
+    Reported beside the §8(d) figure (never inside `achieved`) so that `traffic` can be judged against what the launch
+    really has to move."""
+    q = 1 if q_per_step else 0
+    return 4 * (n + n * n + n * n * (1 + q) + n * m + p * n + p + 4)
 
 
 def lstm_bytes(I, H):
@@ -321,7 +332,7 @@ def main():
 
     # ---- roofline of the LGSSM kernel chain: HIP events around each C-ABI call, eager launches --------------------
     roofline, chain = None, {}
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         eager = Trainer(model, use_graph=False, world_size=1, reference_logging=True)
         for _ in range(3):
             eager.step(x)
@@ -345,6 +356,8 @@ def main():
             if name in per_unit:
                 nbytes = per_unit[name] * B * T
                 ent.update(algorithmic_bytes=nbytes, GBps=round(nbytes / (per_step_us * 1e-6) / 1e9, 2))
+                if name == "elbo":
+                    ent["grad_output_bytes"] = elbo_grad_output_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, q_per_step) * B * T
             chain[name] = ent
         traffic, traffic_src = {}, None
         try:   # HBM bytes per launch from the PMC passes committed under profiles/ (matching config only)

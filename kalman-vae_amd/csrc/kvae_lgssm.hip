@@ -95,8 +95,12 @@ __global__ __launch_bounds__(64) void k_elbo(kvae_lgssm_problem P, const float *
   if (only_if_jitter && levels[0] == 0 && levels[1] == 0) return;
   __shared__ ElboLds<D> L;
   const D d(P.n, P.m, P.p);
-  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
-  elbo_body(d, P, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, have_g ? &G : nullptr, b, t, L);
+  // grid-stride over the (b, t) cells: the backup launch is a few thousand workgroups that normally leave at the line above
+  for (int64_t w = blockIdx.x; w < (int64_t)P.B * P.T; w += gridDim.x) {
+    const int b = (int)(w / P.T), t = (int)(w - (int64_t)b * P.T);
+    elbo_body(d, P, mus, Sigs, eps, terms, levels, ws, g_mus, g_Sigs, have_g ? &G : nullptr, b, t, L);
+    __syncthreads();
+  }
 }
 
 __global__ __launch_bounds__(256) void k_mix_fwd(const float *alpha, const float *base, float *out, int64_t total,
@@ -409,7 +413,7 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
                          want_g ? 1 : 0, s);
     rc = launch_status("k_elbo_n16");
     if (rc) return rc;
-    k_elbo<SDims<16, 16, 2>><<<dim3(grid), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps, terms, (const int32_t *)chol_levels,
+    k_elbo<SDims<16, 16, 2>><<<dim3(grid < 4096 ? grid : 4096), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps, terms, (const int32_t *)chol_levels,
                                                             nullptr, g_mus, g_Sigmas, want_g ? *g : gz, want_g ? 1 : 0, 1);
     return launch_status("k_elbo(jitter fallback)");
   }

@@ -49,9 +49,17 @@ extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgss
 }
 
 // ---- ELBO terms (lgssm_n16_elbo.h): grid = B*T, one wavefront per (sequence, step) ------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (observed, not promised: a wrong guess is only slower), and step t reads
+// A, B, Q and z of step t + 1 as well: give every XCD one contiguous range of (b, t) so that the neighbour's operands are in
+// ITS L2 instead of being fetched over the fabric a second time (bijective for any grid size).
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned wg, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+}
 __global__ __launch_bounds__(64) void k_elbo_probe_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
                                                        float *zst, int32_t *levels) {
-  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = w / P.T, t = w - b * P.T;
   n16::elbo_probe(P, Sig_s, mus, eps, zst, levels, b, t);
 }
 template <bool GRADS, bool HAS_GQ>
@@ -59,7 +67,8 @@ __global__ __launch_bounds__(64) void k_elbo_n16(kvae_lgssm_problem P, const flo
                                                  float *terms, const int32_t *levels, const float *zst, float *g_mus,
                                                  float *g_Sigs, kvae_lgssm_input_grads G) {
   __shared__ n16::ELds L;
-  const int b = blockIdx.x / P.T, t = blockIdx.x - b * P.T;
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = w / P.T, t = w - b * P.T;
   n16::elbo_main<GRADS, HAS_GQ>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t, L);
 }
 

@@ -31,9 +31,9 @@ pmc lgssm_chain_c2 WRITE_SIZE $C2
 pmc lgssm_chain_c5 FETCH_SIZE $C5
 pmc lgssm_chain_c5 WRITE_SIZE $C5
 rm -rf $out/prof_bench_c2
-rocprofv3 --kernel-trace --output-format csv -d $out/prof_bench_c2 -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-steady > $out/prof_bench_c2.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/prof_bench_c2 -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-steady --no-roofline > $out/prof_bench_c2.log 2>&1
 python3 tools/prof_summary.py $(ls $out/prof_bench_c2/*/*kernel_trace.csv | head -1) --steps 10 > $out/${tag}_step_graph_kernel_summary_c2.txt
 rm -rf $out/prof_bench_c5
-rocprofv3 --kernel-trace --output-format csv -d $out/prof_bench_c5 -- python3 bench.py --config c5 --steps 6 --warmup 2 --no-cpu-baseline --no-steady > $out/prof_bench_c5.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/prof_bench_c5 -- python3 bench.py --config c5 --steps 6 --warmup 2 --no-cpu-baseline --no-steady --no-roofline > $out/prof_bench_c5.log 2>&1
 python3 tools/prof_summary.py $(ls $out/prof_bench_c5/*/*kernel_trace.csv | head -1) --steps 4 > $out/${tag}_step_graph_kernel_summary_c5.txt
 ls -la $out/${tag}_*
