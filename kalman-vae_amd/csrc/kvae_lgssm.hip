@@ -932,7 +932,11 @@ int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const fl
 }
 }  // extern "C"
 
-#include "vae_conv_up.h"
+#include "vae_conv_up_wino.h"
+static bool dec_up_wino() {
+  static const int env = getenv("KVAE_WINO") ? atoi(getenv("KVAE_WINO")) : 1;   // 0: direct convolution (A/B runs)
+  return env != 0;
+}
 static inline int64_t dec_up_grid(int64_t N, int32_t side) {
   const int64_t fpi = side == 8 ? 2 : 8, iters = (N + fpi - 1) / fpi;
   return iters < 256 ? (iters < 1 ? 1 : iters) : 256;   // one persistent workgroup per CU
@@ -946,6 +950,13 @@ int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *ou
   if (N < 1 || (N + 256 * 8) * UP_CO * side * side * 4 >= EM_MAX_BYTES) return KVAE_ERR_ARG;   // 32-bit byte offsets
   if (Cin != UP_CI || (side != 8 && side != 4)) return KVAE_ERR_DIMS;
   const dim3 grid((unsigned)dec_up_grid(N, side));
+  if (dec_up_wino()) {   // pairs of workgroups (one per half of the output channels) walk the column sets together
+    const int64_t sets = side == 8 ? N : (N + 3) / 4;
+    const dim3 wgrid((unsigned)(sets < 256 ? sets : 256));
+    if (side == 8) k_dec_up_fwd_wino<8><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    else k_dec_up_fwd_wino<4><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    return launch_status("k_dec_up_fwd_wino");
+  }
   if (side == 8) k_dec_up_fwd<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
   else k_dec_up_fwd<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
   return launch_status("k_dec_up_fwd");

@@ -1,0 +1,241 @@
+// vae_conv_up_wino.h — the decoder's up-sampling blocks (Conv2d(32 -> 128, 3x3, pad 1) + PixelShuffle(2) + ReLU on 4x4 and
+// 8x8 frames, reference kvae/vae/vae.py:92-101) as Winograd F(2x2, 3x3) on the exact-f32 matrix cores: 16 multiplies per
+// 2x2 output tile and channel pair instead of 36, still fp32 throughout (the transforms only add, subtract and halve).
+// The direct kernels of vae_conv_up.h sit at ~85 % of the f32 matrix rate, so fewer multiplies is the only way down.
+//
+//   Y = A^T [ (G g G^T) o (B^T d B) ] A      d: 4x4 input patch of the tile, g: 3x3 filter, o: element-wise over the 16 points,
+//   summed over the input channels BEFORE the output transform: per point p one GEMM  M_p[co][tile] = U_p[co][ci] V_p[ci][tile].
+//
+// Mapping (v_mfma_f32_16x16x4_f32, D[16 co][16 tiles] += A[16 co][4 ci] B[4 ci][16 tiles]):
+//   * a wave owns 16 output channels; its transformed filters U_p[co][ci] - 16 points x 8 k-steps = 128 registers per lane -
+//     stay in registers for the whole (persistent) kernel, transformed once from the raw weights;
+//   * the 16 columns are the 16 tiles of one 8x8 frame (or of four 4x4 frames); lane (j = lane & 15, g = lane >> 4) reads the
+//     4x4 patch of (tile j, channel 4s + g) from a zero-bordered LDS image (eight ds_read_b64, compile-time offsets, no bank
+//     conflicts), transforms it in registers (32 add/sub) and thereby HOLDS the B operands of all 16 points for k-step s;
+//   * 16 accumulators of four registers; the C/D layout gives lane (j, g) the four channels 4g..4g+3 of tile j
+//     = exactly one PixelShuffle output channel and its (dy, dx) sub-pixels: the output transform (24 add/sub per channel),
+//     bias, shuffle and ReLU happen in registers and the 4x4 block of the final image leaves as four 16-byte stores.
+#pragma once
+#include <type_traits>
+#include "vae_conv_up.h"
+
+namespace kvae {
+
+typedef float wn_f4 __attribute__((ext_vector_type(4)));
+#define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int S>
+struct WinoDims {
+  static constexpr int TS = S / 2;                       // tiles per side
+  static constexpr int TPF = TS * TS;                    // 2x2-output tiles per frame (16 or 4)
+  static constexpr int FPC = 16 / TPF;                   // frames per column set (1 or 4)
+  static constexpr int RS = S == 8 ? 12 : 8;             // padded row length: 2 RS ty + 2 tx (+ 4 f) hit 16 distinct bank pairs
+  static constexpr int PLANE = (S + 2) * RS;             // zero-bordered channel plane (120 or 48 floats)
+  static constexpr int FS = 32 * PLANE + (S == 8 ? 0 : 4);   // frame stride (4x4: frames of a column set 4 banks apart)
+  static constexpr int FPI = UpDims<S>::FPI;             // frames per iteration = 2 column sets
+  static constexpr int LDS_IN = FPI * FS;
+};
+
+// rows of B^T d (and, applied again along the other axis, of (B^T d) B): (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+#define WN_BT(o0, o1, o2, o3, d0, d1, d2, d3) do { o0 = (d0) - (d2); o1 = (d1) + (d2); o2 = (d2) - (d1); o3 = (d1) - (d3); } while (0)
+
+// U = G g G^T of one 3x3 filter (row-major g[9]) -> u[16], point p = 4 u + v
+__device__ __forceinline__ void wino_filter(const float *g, float *u) {
+  float r[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    r[0][c] = g[c];
+    r[1][c] = 0.5f * (g[c] + g[3 + c] + g[6 + c]);
+    r[2][c] = 0.5f * (g[c] - g[3 + c] + g[6 + c]);
+    r[3][c] = g[6 + c];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    u[4 * a + 0] = r[a][0];
+    u[4 * a + 1] = 0.5f * (r[a][0] + r[a][1] + r[a][2]);
+    u[4 * a + 2] = 0.5f * (r[a][0] - r[a][1] + r[a][2]);
+    u[4 * a + 3] = r[a][2];
+  }
+}
+
+// A^T M A of one channel: m[p] (16 points) -> y[2a + b]
+__device__ __forceinline__ void wino_out(const float (&m)[16], float (&y)[4]) {
+  float t[2][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    t[0][v] = m[v] + m[4 + v] + m[8 + v];
+    t[1][v] = m[4 + v] - m[8 + v] - m[12 + v];
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    y[2 * a + 0] = t[a][0] + t[a][1] + t[a][2];
+    y[2 * a + 1] = t[a][1] - t[a][2] - t[a][3];
+  }
+}
+
+// the 4x4 patch of one (tile, channel) from the zero-bordered LDS image -> B^T d B, v[4 u + w]
+__device__ __forceinline__ void wino_patch_load(const float *p, int RS, float2 (&d)[4][2]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    d[r][0] = *reinterpret_cast<const float2 *>(p + r * RS);
+    d[r][1] = *reinterpret_cast<const float2 *>(p + r * RS + 2);
+  }
+}
+__device__ __forceinline__ void wino_patch_xform(const float2 (&d)[4][2], float (&v)[16]) {
+  float t[4][4];
+  WN_BT(t[0][0], t[1][0], t[2][0], t[3][0], d[0][0].x, d[1][0].x, d[2][0].x, d[3][0].x);
+  WN_BT(t[0][1], t[1][1], t[2][1], t[3][1], d[0][0].y, d[1][0].y, d[2][0].y, d[3][0].y);
+  WN_BT(t[0][2], t[1][2], t[2][2], t[3][2], d[0][1].x, d[1][1].x, d[2][1].x, d[3][1].x);
+  WN_BT(t[0][3], t[1][3], t[2][3], t[3][3], d[0][1].y, d[1][1].y, d[2][1].y, d[3][1].y);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) WN_BT(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3], t[u][0], t[u][1], t[u][2], t[u][3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward.  A workgroup covers 64 of the 128 output channels (blockIdx & 1), a wave 16 of them: 128 filter registers + 64
+// accumulator registers (32 channels per wave = 256 + 128 spilt into the loop); the two workgroups of a pair walk the same
+// column sets (the second one reads the frames from L2).  The patch transform is SHARED by the four waves through LDS: each
+// wave transforms two of the eight k-steps of the NEXT column set (vt[], rows of 16 points padded to 20 floats: conflict-free
+// ds_read_b128) while all four run the 128 MFMAs of the current one, whose B operands are then plain 16-byte LDS reads.
+// One barrier per column set; input frames and transformed operands are double-buffered.
+// ---------------------------------------------------------------------------------------------------------------
+template <int S>
+struct WinoFwd {
+  using D = UpDims<S>;
+  using Wd = WinoDims<S>;
+  static constexpr int CSX = Wd::FPC * Wd::FS;       // zero-bordered input of one column set (floats)
+  static constexpr int CSG = Wd::FPC * D::XFRAME;    // its 2048 floats in global memory
+  static constexpr int VROW = 20, VSET = 8 * 64 * VROW;
+};
+
+template <int S>
+__global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict__ x, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, float *__restrict__ out, int64_t N) {
+  using D = UpDims<S>;
+  using Wd = WinoDims<S>;
+  using K = WinoFwd<S>;
+  __shared__ float xin[2 * K::CSX];
+  __shared__ __attribute__((aligned(16))) float vt[2 * K::VSET];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int co0 = 16 * wv;                                        // this wave's 16 output channels (8 waves)
+  const int64_t nsets = (N + Wd::FPC - 1) / Wd::FPC, stride = gridDim.x;
+  const __amdgpu_buffer_rsrc_t rx = em_rsrc(x, N * D::XFRAME * 4), ry = em_rsrc(out, N * D::YFRAME * 4);
+  for (int i = tid; i < 2 * K::CSX; i += 512) xin[i] = 0.f;      // the borders stay zero for the whole kernel
+
+  float U[16][8];                                                 // A operands: U_p[co = co0 + j][ci = 4 s + g]
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float *w = W + ((co0 + j) * UP_CI + 4 * s + g) * 9;
+    float gk[9], u[16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gk[t] = w[t];
+    wino_filter(gk, u);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) U[p][s] = u[p];
+  }
+  float bv[4];                                                    // D rows of this lane: co = co0 + 4 g + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = bias[co0 + 4 * g + r];
+
+  // this lane's tile inside a column set: frame fl (4x4: four frames per set), tile (ty, tx)
+  const int fl = S == 8 ? 0 : (j >> 2), ty = S == 8 ? (j >> 2) : ((j >> 1) & 1), tx = S == 8 ? (j & 3) : (j & 1);
+  const int pbase = fl * Wd::FS + g * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx + wv * 4 * Wd::PLANE;   // k-step wv
+  const int vbase_w = (wv * 64 + lane) * K::VROW, vbase_r = lane * K::VROW;
+  // ... and where its 4x4 block of the final [32, 2S, 2S] image goes: channel co0 / 4 + g, rows 4 ty.., columns 4 tx..
+  const int obase = fl * D::YFRAME + (co0 / 4 + g) * 4 * D::PF + 4 * ty * 2 * S + 4 * tx;
+  // staging: two 16-byte pieces of the column set per thread
+  int sdst[1];
+#pragma unroll
+  for (int q = 0; q < 1; ++q) {
+    const int e = (tid + 512 * q) * 4, f = e / D::XFRAME, ci = (e % D::XFRAME) / D::PF, pix = e % D::PF;
+    sdst[q] = f * Wd::FS + ci * Wd::PLANE + (pix / S + 1) * Wd::RS + pix % S + 1;
+  }
+
+  float4 pre[1];
+  auto fetch = [&](int64_t k) {
+#pragma unroll
+    for (int q = 0; q < 1; ++q) pre[q] = em_ld4(rx, (uint32_t)(k * K::CSG + (tid + 512 * q) * 4) * 4u);
+  };
+  auto stage = [&](float *xw) {
+#pragma unroll
+    for (int q = 0; q < 1; ++q) {
+      float *d = xw + sdst[q];
+      d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+    }
+  };
+  auto transform = [&](const float *xr, float *vw) {   // this wave's two k-steps of a column set
+#pragma unroll
+    for (int h = 0; h < 1; ++h) {
+      float2 d[4][2];
+      float v[16];
+      wino_patch_load(xr + pbase + h * 4 * Wd::PLANE, Wd::RS, d);
+      wino_patch_xform(d, v);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4 *>(vw + vbase_w + h * 64 * K::VROW + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+  };
+  auto compute = [&](const float *vr, int64_t k) {     // 128 MFMAs + output transform, bias, shuffle, ReLU of column set k
+    wn_f4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float4 b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4 *>(vr + vbase_r + s * 64 * K::VROW + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[4 * q + 0] = WN_MFMA(U[4 * q + 0][s], b[q].x, acc[4 * q + 0]);
+        acc[4 * q + 1] = WN_MFMA(U[4 * q + 1][s], b[q].y, acc[4 * q + 1]);
+        acc[4 * q + 2] = WN_MFMA(U[4 * q + 2][s], b[q].z, acc[4 * q + 2]);
+        acc[4 * q + 3] = WN_MFMA(U[4 * q + 3][s], b[q].w, acc[4 * q + 3]);
+      }
+    }
+    // register r = sub-pixel (dy, dx) = (r >> 1, r & 1) of shuffle channel co0 / 4 + g
+    const uint32_t o0 = (uint32_t)(k * Wd::FPC * D::YFRAME + obase);
+    float y[4][4];                                   // [r][2a + b]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
+      wino_out(m, y[r]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[r][q] = fmaxf(y[r][q] + bv[r], 0.f);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {               // image row 4 ty + 2a + dy: columns (b, dx) = (0,0) (0,1) (1,0) (1,1)
+        const float4 row = make_float4(y[2 * dy][2 * a], y[2 * dy + 1][2 * a], y[2 * dy][2 * a + 1], y[2 * dy + 1][2 * a + 1]);
+        em_st4(ry, (o0 + (uint32_t)((2 * a + dy) * 2 * S)) * 4u, row);
+      }
+  };
+
+  // pipeline: at step n, xin[(n+1)&1] holds set n+1, vt[n&1] the transformed set n, pre the frames of set n+2
+  int64_t k = blockIdx.x;
+  fetch(k);
+  __syncthreads();                                   // zero fill done
+  stage(xin);
+  fetch(k + stride);
+  __syncthreads();
+  transform(xin, vt);
+  stage(xin + K::CSX);
+  fetch(k + 2 * stride);
+  __syncthreads();
+  for (; k < nsets; k += 2 * stride) {
+    stage(xin);                                      // set n+2 (its buffer held set n, transformed one step ago)
+    fetch(k + 3 * stride);
+    transform(xin + K::CSX, vt + K::VSET);           // set n+1
+    compute(vt, k);                                  // set n
+    __syncthreads();
+    stage(xin + K::CSX);
+    fetch(k + 4 * stride);
+    transform(xin, vt);
+    compute(vt + K::VSET, k + stride);
+    __syncthreads();
+  }
+}
+
+}  // namespace kvae
