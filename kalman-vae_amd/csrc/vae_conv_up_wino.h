@@ -22,6 +22,12 @@
 namespace kvae {
 
 typedef float wn_f4 __attribute__((ext_vector_type(4)));
+#ifdef KVAE_EM_STAMPS   // tools/wino_stamp.hip only: s_memtime stamps of workgroup 0, waves 0 and 4 (the two waves of SIMD 0)
+#define WN_STAMP(slot, k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (slot) < 120) \
+    em_stamps[((threadIdx.x >> 8) * 120 + (slot)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WN_STAMP(slot, k) do {} while (0)
+#endif
 #define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <int S>
@@ -139,33 +145,39 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
 
   // this lane's tile inside a column set: frame fl (4x4: four frames per set), tile (ty, tx)
   const int fl = S == 8 ? 0 : (j >> 2), ty = S == 8 ? (j >> 2) : ((j >> 1) & 1), tx = S == 8 ? (j & 3) : (j & 1);
-  const int pbase = fl * Wd::FS + g * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx + wv * 4 * Wd::PLANE;   // k-step wv
-  const int vbase_w = (wv * 64 + lane) * K::VROW, vbase_r = lane * K::VROW;
+  const int pbase = fl * Wd::FS + g * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx + (2 * (wv & 3)) * 4 * Wd::PLANE;   // k-steps 2 wv, 2 wv + 1 (waves 0-3)
+  const int vbase_w = ((2 * (wv & 3)) * 64 + lane) * K::VROW, vbase_r = lane * K::VROW;
   // ... and where its 4x4 block of the final [32, 2S, 2S] image goes: channel co0 / 4 + g, rows 4 ty.., columns 4 tx..
   const int obase = fl * D::YFRAME + (co0 / 4 + g) * 4 * D::PF + 4 * ty * 2 * S + 4 * tx;
   // staging: two 16-byte pieces of the column set per thread
-  int sdst[1];
+  // The shared work (staging, patch transform) is done by waves 0-3 alone: the SIMD's arbiter favours them, so they reach the
+  // barrier ~3000 cycles before their partners 4-7 anyway (stamps, tools/wino_stamp.hip); the partners only run MFMAs + epilogue.
+  const bool helper = wv < 4;
+  int sdst[2];
 #pragma unroll
-  for (int q = 0; q < 1; ++q) {
-    const int e = (tid + 512 * q) * 4, f = e / D::XFRAME, ci = (e % D::XFRAME) / D::PF, pix = e % D::PF;
+  for (int q = 0; q < 2; ++q) {
+    const int e = ((tid & 255) + 256 * q) * 4, f = e / D::XFRAME, ci = (e % D::XFRAME) / D::PF, pix = e % D::PF;
     sdst[q] = f * Wd::FS + ci * Wd::PLANE + (pix / S + 1) * Wd::RS + pix % S + 1;
   }
 
-  float4 pre[1];
+  float4 pre[2];
   auto fetch = [&](int64_t k) {
+    if (!helper) return;
 #pragma unroll
-    for (int q = 0; q < 1; ++q) pre[q] = em_ld4(rx, (uint32_t)(k * K::CSG + (tid + 512 * q) * 4) * 4u);
+    for (int q = 0; q < 2; ++q) pre[q] = em_ld4(rx, (uint32_t)(k * K::CSG + ((tid & 255) + 256 * q) * 4) * 4u);
   };
   auto stage = [&](float *xw) {
+    if (!helper) return;
 #pragma unroll
-    for (int q = 0; q < 1; ++q) {
+    for (int q = 0; q < 2; ++q) {
       float *d = xw + sdst[q];
       d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
     }
   };
   auto transform = [&](const float *xr, float *vw) {   // this wave's two k-steps of a column set
+    if (!helper) return;
 #pragma unroll
-    for (int h = 0; h < 1; ++h) {
+    for (int h = 0; h < 2; ++h) {
       float2 d[4][2];
       float v[16];
       wino_patch_load(xr + pbase + h * 4 * Wd::PLANE, Wd::RS, d);
@@ -179,11 +191,23 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
     wn_f4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
+    // B operands one k-step ahead, PINNED there: hipcc otherwise sinks each ds_read_b128 to just before its MFMA and the LDS
+    // latency (the helpers' transform traffic included) sits in the MFMA stream twice per k-step (stamps: 70 cycles / MFMA)
+    float4 b[4], bn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4 *>(vr + vbase_r + 4 * q);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      float4 b[4];
+      if (s + 1 < 8) {
+#ifdef WN_DIAG_NOLDS
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4 *>(vr + vbase_r + s * 64 * K::VROW + 4 * q);
+        for (int q = 0; q < 4; ++q) bn[q] = make_float4(b[q].y, b[q].z, b[q].w, b[q].x);
+#else
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bn[q] = *reinterpret_cast<const float4 *>(vr + vbase_r + (s + 1) * 64 * K::VROW + 4 * q);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         acc[4 * q + 0] = WN_MFMA(U[4 * q + 0][s], b[q].x, acc[4 * q + 0]);
@@ -191,6 +215,9 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
         acc[4 * q + 2] = WN_MFMA(U[4 * q + 2][s], b[q].z, acc[4 * q + 2]);
         acc[4 * q + 3] = WN_MFMA(U[4 * q + 3][s], b[q].w, acc[4 * q + 3]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = bn[q];
     }
     // register r = sub-pixel (dy, dx) = (r >> 1, r & 1) of shuffle channel co0 / 4 + g
     const uint32_t o0 = (uint32_t)(k * Wd::FPC * D::YFRAME + obase);
@@ -200,6 +227,7 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
       float m[16];
 #pragma unroll
       for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
+      if (r == 0) WN_STAMP((int)((k - blockIdx.x) / stride / 2), 7);   // (second half overwrites the first: MFMAs done)
       wino_out(m, y[r]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) y[r][q] = fmaxf(y[r][q] + bv[r], 0.f);
@@ -224,18 +252,153 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
   stage(xin + K::CSX);
   fetch(k + 2 * stride);
   __syncthreads();
-  for (; k < nsets; k += 2 * stride) {
+  for (int slot = 0; k < nsets; k += 2 * stride, ++slot) {
+    WN_STAMP(slot, 0);
     stage(xin);                                      // set n+2 (its buffer held set n, transformed one step ago)
     fetch(k + 3 * stride);
     transform(xin + K::CSX, vt + K::VSET);           // set n+1
+    WN_STAMP(slot, 1);
     compute(vt, k);                                  // set n
+    WN_STAMP(slot, 2);
     __syncthreads();
+    WN_STAMP(slot, 3);
     stage(xin + K::CSX);
     fetch(k + 4 * stride);
     transform(xin, vt);
+    WN_STAMP(slot, 4);
     compute(vt + K::VSET, k + stride);
+    WN_STAMP(slot, 5);
+    __syncthreads();
+    WN_STAMP(slot, 6);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// data gradient (8x8 layer): g_x[ci] = sum_co flip(W[co][ci]) (*) gy[co], gy = unshuffle(g_out * (out > 0)) - the same
+// Winograd convolution with the roles of the channels swapped and K = 128.  Wave (hh, kq) = (wv & 1, wv >> 1) produces input
+// channels 16 hh .. 16 hh + 15 from output channels 32 kq .. 32 kq + 31 (128 filter + 64 accumulator registers again); each wave
+// transforms its own patches (the operand set of all 128 channels would not fit in LDS; only the two hh-waves of a kq repeat
+// each other).  g_out and out reach LDS by DMA (buffer_load ... lds, no registers: there are none to spare) one column set
+// ahead, in their own [32][16][16] layout; a short phase between two barriers turns them into masked, un-shuffled,
+// zero-bordered planes, and folds the four K-quarters of the previous set (red[]) into one coalesced 16-byte store per thread.
+// ---------------------------------------------------------------------------------------------------------------
+struct WinoBwd8 {
+  static constexpr int RAW = 8192;                   // floats of g_out (and of out) per frame
+  static constexpr int GY = 128 * WinoDims<8>::PLANE;
+  static constexpr int RED = 2048;                   // one K-quarter's partial g_x of a frame
+  static constexpr int LDS = 2 * RAW + GY + 4 * RED;
+};
+
+__global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__restrict__ W, const float *__restrict__ out,
+                                                               const float *__restrict__ g_out, float *__restrict__ g_x, int64_t N) {
+  constexpr int S = 8;
+  using D = UpDims<S>;
+  using Wd = WinoDims<S>;
+  using K = WinoBwd8;
+  // two objects on purpose: the DMA target must be provably distinct from the arrays the MFMA phase reads, or hipcc drains
+  // the DMA (s_waitcnt vmcnt(0)) in front of the first ds_read after it
+  __shared__ __attribute__((aligned(16))) float raw[2 * K::RAW];
+  __shared__ __attribute__((aligned(16))) float work[K::GY + 4 * K::RED];
+  float *rawg = raw, *rawo = raw + K::RAW, *gy = work, *red = work + K::GY;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4, hh = wv & 1, kq = wv >> 1;
+  const int64_t stride = gridDim.x;
+  const __amdgpu_buffer_rsrc_t rg = em_rsrc(g_out, N * D::YFRAME * 4), ro = em_rsrc(out, N * D::YFRAME * 4),
+                               rgx = em_rsrc(g_x, N * D::XFRAME * 4);
+  for (int i = tid; i < K::GY; i += 512) gy[i] = 0.f;             // the borders stay zero for the whole kernel
+
+  float U[16][8];                                                 // A operands: flip(W)[co = 32 kq + 4 s + g][ci = 16 hh + j]
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float *w = W + ((32 * kq + 4 * s + g) * UP_CI + 16 * hh + j) * 9;
+    float gk[9], u[16];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gk[t] = w[8 - t];
+    wino_filter(gk, u);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) U[p][s] = u[p];
+  }
+  const int ty = j >> 2, tx = j & 3;
+  const int pbase = (32 * kq + g) * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx;
+  const int rbase = kq * K::RED + (16 * hh + 4 * g) * 64 + 2 * ty * 8 + 2 * tx;
+
+  // (the staging phases recompute their addresses from an opaque copy of tid: hoisted out of the loop they would sit in
+  //  registers through the MFMA phase, which has none to spare)
+  auto dma = [&](int64_t k) {                         // eight 8 KB pieces: g_out then out of frame k
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t off = (uint32_t)(k * K::RAW + (t2 + 512 * q) * 4) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(rawg + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+    }
+  };
+  auto convert = [&]() {                              // raw -> masked, un-shuffled, zero-bordered planes (co = 4 c + 2 dy + dx)
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = (t2 + 512 * q) * 4, c = e >> 8, y = (e >> 4) & 15, xx = e & 15;
+      const float4 gv = *reinterpret_cast<const float4 *>(rawg + e), ov = *reinterpret_cast<const float4 *>(rawo + e);
+      float *d = gy + (4 * c + 2 * (y & 1)) * Wd::PLANE + ((y >> 1) + 1) * Wd::RS + (xx >> 1) + 1;
+      d[0] = ov.x > 0.f ? gv.x : 0.f;
+      d[Wd::PLANE] = ov.y > 0.f ? gv.y : 0.f;
+      d[1] = ov.z > 0.f ? gv.z : 0.f;
+      d[Wd::PLANE + 1] = ov.w > 0.f ? gv.w : 0.f;
+    }
+  };
+  uint32_t done = 0x80000000u;                        // byte offset of the frame whose partials sit in red[] (none yet)
+  auto fold = [&]() {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const float4 a = *reinterpret_cast<const float4 *>(red + 4 * t2), b = *reinterpret_cast<const float4 *>(red + K::RED + 4 * t2),
+                 c = *reinterpret_cast<const float4 *>(red + 2 * K::RED + 4 * t2), d = *reinterpret_cast<const float4 *>(red + 3 * K::RED + 4 * t2);
+    em_st4(rgx, done + (uint32_t)t2 * 16u, make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                                                        (a.w + b.w) + (c.w + d.w)));
+  };
+  auto compute = [&]() {
+    wn_f4 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
+    float2 d[4][2], dn[4][2];
+    wino_patch_load(gy + pbase, Wd::RS, d);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                     // the next patch is requested before this k-step's MFMAs (pinned, as above)
+      if (s + 1 < 8) wino_patch_load(gy + pbase + (s + 1) * 4 * Wd::PLANE, Wd::RS, dn);
+      float v[16];
+      wino_patch_xform(d, v);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < 16; ++p) acc[p] = WN_MFMA(U[p][s], v[p], acc[p]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r][0] = dn[r][0], d[r][1] = dn[r][1];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                     // D row r: input channel 16 hh + 4 g + r; pixels (2 ty + a, 2 tx + b)
+      float m[16], y[4];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
+      wino_out(m, y);
+      *reinterpret_cast<float2 *>(red + rbase + r * 64) = make_float2(y[0], y[1]);
+      *reinterpret_cast<float2 *>(red + rbase + r * 64 + 8) = make_float2(y[2], y[3]);
+    }
+  };
+
+  int64_t k = blockIdx.x;
+  dma(k);
+  __syncthreads();                                    // zero fill done, frame k landed (the barrier's fence drains the DMA)
+  for (; k < N; k += stride) {
+    convert();
+    fold();                                           // previous frame's four partial sums -> g_x
+    __syncthreads();
+    dma(k + stride);                                  // raw buffers are free again; lands behind the MFMAs
+    __builtin_amdgcn_sched_barrier(0);                // (issued HERE, not sunk to the end of the phase)
+    compute();
+    done = (uint32_t)(k * D::XFRAME) * 4u;
     __syncthreads();
   }
+  fold();
 }
 
 }  // namespace kvae
