@@ -975,7 +975,8 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
     const int rc = launch_status("k_dec_up_bwd_data");
     if (rc) return rc;
   }
-  if (side == 8) k_dec_up_wrw<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+  if (side == 8 && dec_up_wino()) k_dec_up_wrw_wino8<<<grid, dim3(512), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+  else if (side == 8) k_dec_up_wrw<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
   else k_dec_up_wrw<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
   return launch_status("k_dec_up_wrw");
 }

@@ -401,4 +401,169 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__re
   fold();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient (8x8 layer): dW[co][ci] = G^T Z G,  Z_p[co][ci] = sum over frames and tiles of (A gy A^T)_p[co][tile] (B^T x B)_p[ci][tile]
+// - the adjoint of the forward's element-wise product, so again 16 multiplies per (tile, channel pair) instead of 36.  The tiles
+// are the K dimension now (four per MFMA); wave wv keeps Z for output channels 16 wv .. 16 wv + 15, all 32 input channels and all
+// 16 points in 128 accumulator registers for the whole kernel and applies G^T . G once at the end.  Per frame: the x patches are
+// transformed once for the whole workgroup (one patch per thread, through LDS, as in the forward); every wave expands its own
+// 2x2 tiles of gy = unshuffle(g_out * (out > 0)), which a short phase between two barriers lays out so that a lane's tile is
+// one ds_read_b128 (g_out / out arrive by DMA, x through 4 registers, one frame ahead).
+// ---------------------------------------------------------------------------------------------------------------
+struct WinoWrw8 {
+  static constexpr int RAW = 8192;                   // floats of g_out (and of out) per frame
+  static constexpr int GY4 = 8192;                   // [ks 4][co 128][tx 4][2a + b]
+  static constexpr int XP = 130, XPL = 32 * XP;      // zero-bordered x planes, stride 130: 16 channels -> 16 distinct bank pairs
+  static constexpr int VROW = 20, VSET = 8 * 64 * VROW;
+};
+
+__global__ __launch_bounds__(512) void k_dec_up_wrw_wino8(const float *__restrict__ x, const float *__restrict__ out,
+                                                          const float *__restrict__ g_out, float *__restrict__ w_partials,
+                                                          float *__restrict__ b_partials, int64_t N) {
+  constexpr int S = 8;
+  using D = UpDims<S>;
+  using Wd = WinoDims<S>;
+  using K = WinoWrw8;
+  __shared__ __attribute__((aligned(16))) float raw[2 * K::RAW];                        // DMA targets (own object: see bwd_data)
+  __shared__ __attribute__((aligned(16))) float work[K::GY4 + K::XPL + K::VSET];
+  float *rawg = raw, *rawo = raw + K::RAW, *gy4 = work, *xp = work + K::GY4, *vt = xp + K::XPL;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int64_t stride = gridDim.x;
+  const __amdgpu_buffer_rsrc_t rx = em_rsrc(x, N * D::XFRAME * 4), rg = em_rsrc(g_out, N * D::YFRAME * 4),
+                               ro = em_rsrc(out, N * D::YFRAME * 4);
+  for (int i = tid; i < K::XPL; i += 512) xp[i] = 0.f;            // the borders stay zero for the whole kernel
+
+  wn_f4 acc[16][2];                                               // Z_p[co = 16 wv + 4 g + r][ci = 16 nh + j]
+#pragma unroll
+  for (int p = 0; p < 16; ++p) acc[p][0] = acc[p][1] = wn_f4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  auto dma = [&](int64_t k) {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t off = (uint32_t)(k * K::RAW + (t2 + 512 * q) * 4) * 4u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(rawg + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+    }
+  };
+  float4 pre;
+  auto fetch = [&](int64_t k) {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    pre = em_ld4(rx, (uint32_t)(k * D::XFRAME + t2 * 4) * 4u);
+  };
+  auto stage = [&]() {                                // x[ci][h][w4..w4+3] -> plane ci, row h + 1, column w + 1
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const int e = t2 * 4, ci = e >> 6, pix = e & 63;
+    float *d = xp + ci * K::XP + ((pix >> 3) + 1) * Wd::RS + (pix & 7) + 1;
+    d[0] = pre.x; d[1] = pre.y; d[2] = pre.z; d[3] = pre.w;
+  };
+  auto convert = [&]() {                              // raw -> gy4[ks = ty][co][tx][2a + b], masked (co = 4 c + 2 dy + dx)
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = (t2 + 512 * q) * 4, c = e >> 8, y = (e >> 4) & 15, xx = e & 15;
+      const float4 gv = *reinterpret_cast<const float4 *>(rawg + e), ov = *reinterpret_cast<const float4 *>(rawo + e);
+      // row y = 4 ty + 2 a + dy, columns xx + (0..3) = 4 tx + 2 b + dx
+      float *d = gy4 + (((y >> 2) * 128 + 4 * c + 2 * (y & 1)) * 4 + (xx >> 2)) * 4 + 2 * ((y >> 1) & 1);
+      *reinterpret_cast<float2 *>(d) = make_float2(ov.x > 0.f ? gv.x : 0.f, ov.z > 0.f ? gv.z : 0.f);          // dx = 0: b = 0, 1
+      *reinterpret_cast<float2 *>(d + 16) = make_float2(ov.y > 0.f ? gv.y : 0.f, ov.w > 0.f ? gv.w : 0.f);     // dx = 1 (next co)
+    }
+  };
+  // operand row of this thread in vt: (ks = wv >> 1, nh = wv & 1, lane): channel 16 nh + j, tile (ty, tx) = (ks, g)
+  auto transform = [&]() {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const int l2 = t2 & 63, w2 = t2 >> 6;
+    float2 d[4][2];
+    float v[16];
+    wino_patch_load(xp + (16 * (w2 & 1) + (l2 & 15)) * K::XP + 2 * (w2 >> 1) * Wd::RS + 2 * (l2 >> 4), Wd::RS, d);
+    wino_patch_xform(d, v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4 *>(vt + t2 * K::VROW + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // A operands: (A gy A^T)_p of (co = 16 wv + j, tile (ks, g)); gy tile = (y00, y01, y10, y11)
+      const float4 t = *reinterpret_cast<const float4 *>(gy4 + ((ks * 128 + 16 * wv + j) * 4 + g) * 4);
+      bsum += (t.x + t.y) + (t.z + t.w);
+      float yh[16];
+      {
+        const float r0[2] = {t.x, t.y}, r1[2] = {t.x + t.z, t.y + t.w}, r2[2] = {t.x - t.z, t.y - t.w}, r3[2] = {-t.z, -t.w};
+        const float *rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          yh[4 * u + 0] = rr[u][0];
+          yh[4 * u + 1] = rr[u][0] + rr[u][1];
+          yh[4 * u + 2] = rr[u][0] - rr[u][1];
+          yh[4 * u + 3] = -rr[u][1];
+        }
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        float4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4 *>(vt + ((2 * ks + nh) * 64 + lane) * K::VROW + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[4 * q + 0][nh] = WN_MFMA(yh[4 * q + 0], b[q].x, acc[4 * q + 0][nh]);
+          acc[4 * q + 1][nh] = WN_MFMA(yh[4 * q + 1], b[q].y, acc[4 * q + 1][nh]);
+          acc[4 * q + 2][nh] = WN_MFMA(yh[4 * q + 2], b[q].z, acc[4 * q + 2][nh]);
+          acc[4 * q + 3][nh] = WN_MFMA(yh[4 * q + 3], b[q].w, acc[4 * q + 3][nh]);
+        }
+      }
+    }
+  };
+
+  int64_t k = blockIdx.x;
+  dma(k);
+  fetch(k);
+  __syncthreads();                                    // zero fill done, raw(k) landed
+  stage();
+  fetch(k + stride);
+  __syncthreads();
+  for (; k < N; k += stride) {
+    convert();                                        // raw(k) -> gy4
+    transform();                                      // planes(k) -> vt
+    __syncthreads();
+    dma(k + stride);
+    __builtin_amdgcn_sched_barrier(0);
+    stage();                                          // planes <- x(k + stride)
+    fetch(k + 2 * stride);
+    compute();
+    __syncthreads();
+  }
+  // G^T Z G per (co, ci), partial sums of this workgroup
+  float *wp = w_partials + (int64_t)blockIdx.x * UP_W;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t[3][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float z0 = acc[v][nh][r], z1 = acc[4 + v][nh][r], z2 = acc[8 + v][nh][r], z3 = acc[12 + v][nh][r];
+        t[0][v] = z0 + 0.5f * (z1 + z2);
+        t[1][v] = 0.5f * (z1 - z2);
+        t[2][v] = 0.5f * (z1 + z2) + z3;
+      }
+      float *o = wp + ((16 * wv + 4 * g + r) * UP_CI + 16 * nh + j) * 9;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        o[3 * a + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        o[3 * a + 1] = 0.5f * (t[a][1] - t[a][2]);
+        o[3 * a + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+      }
+    }
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  if (g == 0) b_partials[(int64_t)blockIdx.x * UP_CO + 16 * wv + j] = bsum;
+}
+
 }  // namespace kvae
