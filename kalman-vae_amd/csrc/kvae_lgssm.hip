@@ -968,15 +968,21 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
   if (Cin != UP_CI || (side != 8 && side != 4)) return KVAE_ERR_DIMS;
   const dim3 grid((unsigned)dec_up_grid(N, side));
   if (g_x) {
-    if (side == 8 && dec_up_wino())
-      k_dec_up_bwd_data_wino8<<<dim3((unsigned)(N < 256 ? N : 256)), dim3(512), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
+    const int64_t sets = side == 8 ? N : (N + 3) / 4;
+    const dim3 wgrid((unsigned)(sets < 256 ? sets : 256));
+    if (dec_up_wino() && side == 8) k_dec_up_bwd_data_wino<8><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
+    else if (dec_up_wino()) k_dec_up_bwd_data_wino<4><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
     else if (side == 8) k_dec_up_bwd_data<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
     else k_dec_up_bwd_data<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
     const int rc = launch_status("k_dec_up_bwd_data");
     if (rc) return rc;
   }
-  if (side == 8 && dec_up_wino()) k_dec_up_wrw_wino8<<<grid, dim3(512), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
-  else if (side == 8) k_dec_up_wrw<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+  if (dec_up_wino()) {
+    if (side == 8) k_dec_up_wrw_wino<8><<<grid, dim3(512), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+    else k_dec_up_wrw_wino<4><<<grid, dim3(512), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
+    return launch_status("k_dec_up_wrw_wino");
+  }
+  if (side == 8) k_dec_up_wrw<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
   else k_dec_up_wrw<4><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
   return launch_status("k_dec_up_wrw");
 }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// data gradient (8x8 layer): g_x[ci] = sum_co flip(W[co][ci]) (*) gy[co], gy = unshuffle(g_out * (out > 0)) - the same
+// data gradient: g_x[ci] = sum_co flip(W[co][ci]) (*) gy[co], gy = unshuffle(g_out * (out > 0)) - the same
 // Winograd convolution with the roles of the channels swapped and K = 128.  Wave (hh, kq) = (wv & 1, wv >> 1) produces input
 // channels 16 hh .. 16 hh + 15 from output channels 32 kq .. 32 kq + 31 (128 filter + 64 accumulator registers again); each wave
 // transforms its own patches (the operand set of all 128 channels would not fit in LDS; only the two hh-waves of a kq repeat
@@ -282,26 +282,32 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
 // ahead, in their own [32][16][16] layout; a short phase between two barriers turns them into masked, un-shuffled,
 // zero-bordered planes, and folds the four K-quarters of the previous set (red[]) into one coalesced 16-byte store per thread.
 // ---------------------------------------------------------------------------------------------------------------
-struct WinoBwd8 {
-  static constexpr int RAW = 8192;                   // floats of g_out (and of out) per frame
-  static constexpr int GY = 128 * WinoDims<8>::PLANE;
-  static constexpr int RED = 2048;                   // one K-quarter's partial g_x of a frame
-  static constexpr int LDS = 2 * RAW + GY + 4 * RED;
+// 4x4 layer: a column set is four frames; their planes keep the left / right border columns but NOT the top / bottom border
+// rows (4 x 6 floats instead of 6 x 6: 128 channels x 4 frames must fit beside the DMA buffers) - those two patch rows are read
+// from beyond the LDS allocation, which returns zeros (EM_OOB); frames sit 24 banks apart (16 distinct bank pairs per 16 lanes).
+template <int S>
+struct WinoBwd {
+  static constexpr int RAW = 8192;                   // floats of g_out (and of out) per column set
+  static constexpr int RS = S == 8 ? 12 : 6;
+  static constexpr int PLANE = S == 8 ? 120 : 24;
+  static constexpr int FSB = 128 * PLANE + (S == 8 ? 0 : 24);
+  static constexpr int GY = WinoDims<S>::FPC * FSB;
+  static constexpr int RED = 2048;                   // one K-quarter's partial g_x of a column set
 };
 
-__global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__restrict__ W, const float *__restrict__ out,
-                                                               const float *__restrict__ g_out, float *__restrict__ g_x, int64_t N) {
-  constexpr int S = 8;
+template <int S>
+__global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino(const float *__restrict__ W, const float *__restrict__ out,
+                                                              const float *__restrict__ g_out, float *__restrict__ g_x, int64_t N) {
   using D = UpDims<S>;
   using Wd = WinoDims<S>;
-  using K = WinoBwd8;
+  using K = WinoBwd<S>;
   // two objects on purpose: the DMA target must be provably distinct from the arrays the MFMA phase reads, or hipcc drains
   // the DMA (s_waitcnt vmcnt(0)) in front of the first ds_read after it
   __shared__ __attribute__((aligned(16))) float raw[2 * K::RAW];
   __shared__ __attribute__((aligned(16))) float work[K::GY + 4 * K::RED];
   float *rawg = raw, *rawo = raw + K::RAW, *gy = work, *red = work + K::GY;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4, hh = wv & 1, kq = wv >> 1;
-  const int64_t stride = gridDim.x;
+  const int64_t stride = gridDim.x, nsets = (N + Wd::FPC - 1) / Wd::FPC;
   const __amdgpu_buffer_rsrc_t rg = em_rsrc(g_out, N * D::YFRAME * 4), ro = em_rsrc(out, N * D::YFRAME * 4),
                                rgx = em_rsrc(g_x, N * D::XFRAME * 4);
   for (int i = tid; i < K::GY; i += 512) gy[i] = 0.f;             // the borders stay zero for the whole kernel
@@ -317,13 +323,19 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__re
 #pragma unroll
     for (int p = 0; p < 16; ++p) U[p][s] = u[p];
   }
-  const int ty = j >> 2, tx = j & 3;
-  const int pbase = (32 * kq + g) * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx;
-  const int rbase = kq * K::RED + (16 * hh + 4 * g) * 64 + 2 * ty * 8 + 2 * tx;
+  // this lane's tile: frame fl of the set, tile (ty, tx); patch row r of k-step s starts at gy[prow[r] + s * 4 * PLANE]
+  const int fl = S == 8 ? 0 : (j >> 2), ty = S == 8 ? (j >> 2) : ((j >> 1) & 1), tx = S == 8 ? (j & 3) : (j & 1);
+  int prow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = S == 8 ? 2 * ty + r : 2 * ty - 1 + r;         // 8x8: planes carry their border rows; 4x4: rows -1 and 4 read zeros
+    prow[r] = (S == 4 && (row < 0 || row > 3)) ? EM_OOB : fl * K::FSB + (32 * kq + g) * K::PLANE + row * K::RS + 2 * tx;
+  }
+  const int rbase = kq * K::RED + fl * D::XFRAME + (16 * hh + 4 * g) * D::PF + 2 * ty * S + 2 * tx;
 
   // (the staging phases recompute their addresses from an opaque copy of tid: hoisted out of the loop they would sit in
   //  registers through the MFMA phase, which has none to spare)
-  auto dma = [&](int64_t k) {                         // eight 8 KB pieces: g_out then out of frame k
+  auto dma = [&](int64_t k) {                         // eight 8 KB pieces: g_out then out of column set k
     int t2 = tid;
     asm volatile("" : "+v"(t2));
 #pragma unroll
@@ -333,21 +345,28 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__re
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
     }
   };
-  auto convert = [&]() {                              // raw -> masked, un-shuffled, zero-bordered planes (co = 4 c + 2 dy + dx)
+  auto convert = [&]() {                              // raw -> masked, un-shuffled planes with zero borders (co = 4 c + 2 dy + dx)
     int t2 = tid;
     asm volatile("" : "+v"(t2));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int e = (t2 + 512 * q) * 4, c = e >> 8, y = (e >> 4) & 15, xx = e & 15;
+      const int e = (t2 + 512 * q) * 4;
       const float4 gv = *reinterpret_cast<const float4 *>(rawg + e), ov = *reinterpret_cast<const float4 *>(rawo + e);
-      float *d = gy + (4 * c + 2 * (y & 1)) * Wd::PLANE + ((y >> 1) + 1) * Wd::RS + (xx >> 1) + 1;
+      float *d;
+      if constexpr (S == 8) {
+        const int c = e >> 8, y = (e >> 4) & 15, xx = e & 15;
+        d = gy + (4 * c + 2 * (y & 1)) * K::PLANE + ((y >> 1) + 1) * K::RS + (xx >> 1) + 1;
+      } else {
+        const int f = e >> 11, c = (e >> 6) & 31, y = (e >> 3) & 7, xx = e & 7;
+        d = gy + f * K::FSB + (4 * c + 2 * (y & 1)) * K::PLANE + (y >> 1) * K::RS + (xx >> 1) + 1;
+      }
       d[0] = ov.x > 0.f ? gv.x : 0.f;
-      d[Wd::PLANE] = ov.y > 0.f ? gv.y : 0.f;
+      d[K::PLANE] = ov.y > 0.f ? gv.y : 0.f;
       d[1] = ov.z > 0.f ? gv.z : 0.f;
-      d[Wd::PLANE + 1] = ov.w > 0.f ? gv.w : 0.f;
+      d[K::PLANE + 1] = ov.w > 0.f ? gv.w : 0.f;
     }
   };
-  uint32_t done = 0x80000000u;                        // byte offset of the frame whose partials sit in red[] (none yet)
+  uint32_t done = 0x80000000u;                        // byte offset of the set whose partials sit in red[] (none yet)
   auto fold = [&]() {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
@@ -356,15 +375,23 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__re
     em_st4(rgx, done + (uint32_t)t2 * 16u, make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
                                                         (a.w + b.w) + (c.w + d.w)));
   };
+  auto patch = [&](int s, float2 (&d)[4][2]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *p = gy + prow[r] + s * 4 * K::PLANE;
+      d[r][0] = *reinterpret_cast<const float2 *>(p);
+      d[r][1] = *reinterpret_cast<const float2 *>(p + 2);
+    }
+  };
   auto compute = [&]() {
     wn_f4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
     float2 d[4][2], dn[4][2];
-    wino_patch_load(gy + pbase, Wd::RS, d);
+    patch(0, d);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {                     // the next patch is requested before this k-step's MFMAs (pinned, as above)
-      if (s + 1 < 8) wino_patch_load(gy + pbase + (s + 1) * 4 * Wd::PLANE, Wd::RS, dn);
+      if (s + 1 < 8) patch(s + 1, dn);
       float v[16];
       wino_patch_xform(d, v);
       __builtin_amdgcn_sched_barrier(0);
@@ -380,29 +407,29 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__re
 #pragma unroll
       for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
       wino_out(m, y);
-      *reinterpret_cast<float2 *>(red + rbase + r * 64) = make_float2(y[0], y[1]);
-      *reinterpret_cast<float2 *>(red + rbase + r * 64 + 8) = make_float2(y[2], y[3]);
+      *reinterpret_cast<float2 *>(red + rbase + r * D::PF) = make_float2(y[0], y[1]);
+      *reinterpret_cast<float2 *>(red + rbase + r * D::PF + S) = make_float2(y[2], y[3]);
     }
   };
 
   int64_t k = blockIdx.x;
   dma(k);
-  __syncthreads();                                    // zero fill done, frame k landed (the barrier's fence drains the DMA)
-  for (; k < N; k += stride) {
+  __syncthreads();                                    // zero fill done, set k landed (the barrier's fence drains the DMA)
+  for (; k < nsets; k += stride) {
     convert();
-    fold();                                           // previous frame's four partial sums -> g_x
+    fold();                                           // previous set's four partial sums -> g_x
     __syncthreads();
     dma(k + stride);                                  // raw buffers are free again; lands behind the MFMAs
     __builtin_amdgcn_sched_barrier(0);                // (issued HERE, not sunk to the end of the phase)
     compute();
-    done = (uint32_t)(k * D::XFRAME) * 4u;
+    done = (uint32_t)(k * 2048) * 4u;
     __syncthreads();
   }
   fold();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight gradient (8x8 layer): dW[co][ci] = G^T Z G,  Z_p[co][ci] = sum over frames and tiles of (A gy A^T)_p[co][tile] (B^T x B)_p[ci][tile]
+// weight gradient: dW[co][ci] = G^T Z G,  Z_p[co][ci] = sum over frames and tiles of (A gy A^T)_p[co][tile] (B^T x B)_p[ci][tile]
 // - the adjoint of the forward's element-wise product, so again 16 multiplies per (tile, channel pair) instead of 36.  The tiles
 // are the K dimension now (four per MFMA); wave wv keeps Z for output channels 16 wv .. 16 wv + 15, all 32 input channels and all
 // 16 points in 128 accumulator registers for the whole kernel and applies G^T . G once at the end.  Per frame: the x patches are
@@ -410,25 +437,28 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino8(const float *__re
 // 2x2 tiles of gy = unshuffle(g_out * (out > 0)), which a short phase between two barriers lays out so that a lane's tile is
 // one ds_read_b128 (g_out / out arrive by DMA, x through 4 registers, one frame ahead).
 // ---------------------------------------------------------------------------------------------------------------
-struct WinoWrw8 {
-  static constexpr int RAW = 8192;                   // floats of g_out (and of out) per frame
-  static constexpr int GY4 = 8192;                   // [ks 4][co 128][tx 4][2a + b]
-  static constexpr int XP = 130, XPL = 32 * XP;      // zero-bordered x planes, stride 130: 16 channels -> 16 distinct bank pairs
+template <int S>
+struct WinoWrw {
+  static constexpr int RAW = 8192;                   // floats of g_out (and of out) per column set (one 8x8 or four 4x4 frames)
+  static constexpr int GY4 = 8192;                   // [ks 4][co 128][tile in group 4][2a + b]
+  static constexpr int RS = S == 8 ? 12 : 6;         // row length of the zero-bordered x planes
+  static constexpr int XP = S == 8 ? 130 : 38;       // plane stride: 16 channels -> 16 distinct bank pairs (130 = 2, 38 = 6 mod 32)
+  static constexpr int XPL = WinoDims<S>::FPC * 32 * XP;
   static constexpr int VROW = 20, VSET = 8 * 64 * VROW;
 };
 
-__global__ __launch_bounds__(512) void k_dec_up_wrw_wino8(const float *__restrict__ x, const float *__restrict__ out,
-                                                          const float *__restrict__ g_out, float *__restrict__ w_partials,
-                                                          float *__restrict__ b_partials, int64_t N) {
-  constexpr int S = 8;
+template <int S>
+__global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict__ x, const float *__restrict__ out,
+                                                         const float *__restrict__ g_out, float *__restrict__ w_partials,
+                                                         float *__restrict__ b_partials, int64_t N) {
   using D = UpDims<S>;
   using Wd = WinoDims<S>;
-  using K = WinoWrw8;
+  using K = WinoWrw<S>;
   __shared__ __attribute__((aligned(16))) float raw[2 * K::RAW];                        // DMA targets (own object: see bwd_data)
   __shared__ __attribute__((aligned(16))) float work[K::GY4 + K::XPL + K::VSET];
   float *rawg = raw, *rawo = raw + K::RAW, *gy4 = work, *xp = work + K::GY4, *vt = xp + K::XPL;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
-  const int64_t stride = gridDim.x;
+  const int64_t stride = gridDim.x, nsets = (N + Wd::FPC - 1) / Wd::FPC;
   const __amdgpu_buffer_rsrc_t rx = em_rsrc(x, N * D::XFRAME * 4), rg = em_rsrc(g_out, N * D::YFRAME * 4),
                                ro = em_rsrc(out, N * D::YFRAME * 4);
   for (int i = tid; i < K::XPL; i += 512) xp[i] = 0.f;            // the borders stay zero for the whole kernel
@@ -452,36 +482,46 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino8(const float *__restric
   auto fetch = [&](int64_t k) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    pre = em_ld4(rx, (uint32_t)(k * D::XFRAME + t2 * 4) * 4u);
+    pre = em_ld4(rx, (uint32_t)(k * 2048 + t2 * 4) * 4u);
   };
-  auto stage = [&]() {                                // x[ci][h][w4..w4+3] -> plane ci, row h + 1, column w + 1
+  auto stage = [&]() {                                // x[f][ci][h][w..w+3] -> plane (f, ci), row h + 1, column w + 1
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    const int e = t2 * 4, ci = e >> 6, pix = e & 63;
-    float *d = xp + ci * K::XP + ((pix >> 3) + 1) * Wd::RS + (pix & 7) + 1;
+    const int e = t2 * 4, pl = e / D::PF, pix = e % D::PF;         // plane index f * 32 + ci
+    float *d = xp + pl * K::XP + (pix / S + 1) * K::RS + pix % S + 1;
     d[0] = pre.x; d[1] = pre.y; d[2] = pre.z; d[3] = pre.w;
   };
-  auto convert = [&]() {                              // raw -> gy4[ks = ty][co][tx][2a + b], masked (co = 4 c + 2 dy + dx)
+  // raw -> gy4[ks][co][tile in group][2a + b], masked (co = 4 c + 2 dy + dx; row y = 4 ty + 2 a + dy, column xx = 4 tx + 2 b + dx).
+  // 8x8: k-step = tile row ty, tile in group = tx; 4x4: k-step = frame of the set, tile in group = 2 ty + tx.
+  auto convert = [&]() {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int e = (t2 + 512 * q) * 4, c = e >> 8, y = (e >> 4) & 15, xx = e & 15;
+      const int e = (t2 + 512 * q) * 4;
       const float4 gv = *reinterpret_cast<const float4 *>(rawg + e), ov = *reinterpret_cast<const float4 *>(rawo + e);
-      // row y = 4 ty + 2 a + dy, columns xx + (0..3) = 4 tx + 2 b + dx
-      float *d = gy4 + (((y >> 2) * 128 + 4 * c + 2 * (y & 1)) * 4 + (xx >> 2)) * 4 + 2 * ((y >> 1) & 1);
+      int ks, co, tg, a;
+      if constexpr (S == 8) {
+        const int c = e >> 8, y = (e >> 4) & 15, xx = e & 15;
+        ks = y >> 2, co = 4 * c + 2 * (y & 1), tg = xx >> 2, a = (y >> 1) & 1;
+      } else {
+        const int f = e >> 11, c = (e >> 6) & 31, y = (e >> 3) & 7, xx = e & 7;
+        ks = f, co = 4 * c + 2 * (y & 1), tg = 2 * (y >> 2) + (xx >> 2), a = (y >> 1) & 1;
+      }
+      float *d = gy4 + ((ks * 128 + co) * 4 + tg) * 4 + 2 * a;
       *reinterpret_cast<float2 *>(d) = make_float2(ov.x > 0.f ? gv.x : 0.f, ov.z > 0.f ? gv.z : 0.f);          // dx = 0: b = 0, 1
       *reinterpret_cast<float2 *>(d + 16) = make_float2(ov.y > 0.f ? gv.y : 0.f, ov.w > 0.f ? gv.w : 0.f);     // dx = 1 (next co)
     }
   };
-  // operand row of this thread in vt: (ks = wv >> 1, nh = wv & 1, lane): channel 16 nh + j, tile (ty, tx) = (ks, g)
+  // operand row of this thread in vt: (ks = wv >> 1, nh = wv & 1, lane): channel 16 nh + j, tile g of k-step ks
   auto transform = [&]() {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
-    const int l2 = t2 & 63, w2 = t2 >> 6;
+    const int l2 = t2 & 63, w2 = t2 >> 6, ks = w2 >> 1, ci = 16 * (w2 & 1) + (l2 & 15), tg = l2 >> 4;
+    const int pb = S == 8 ? ci * K::XP + 2 * ks * K::RS + 2 * tg : (ks * 32 + ci) * K::XP + 2 * (tg >> 1) * K::RS + 2 * (tg & 1);
     float2 d[4][2];
     float v[16];
-    wino_patch_load(xp + (16 * (w2 & 1) + (l2 & 15)) * K::XP + 2 * (w2 >> 1) * Wd::RS + 2 * (l2 >> 4), Wd::RS, d);
+    wino_patch_load(xp + pb, K::RS, d);
     wino_patch_xform(d, v);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -490,7 +530,7 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino8(const float *__restric
   auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      // A operands: (A gy A^T)_p of (co = 16 wv + j, tile (ks, g)); gy tile = (y00, y01, y10, y11)
+      // A operands: (A gy A^T)_p of (co = 16 wv + j, tile g of the k-step); gy tile = (y00, y01, y10, y11)
       const float4 t = *reinterpret_cast<const float4 *>(gy4 + ((ks * 128 + 16 * wv + j) * 4 + g) * 4);
       bsum += (t.x + t.y) + (t.z + t.w);
       float yh[16];
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino8(const float *__restric
   stage();
   fetch(k + stride);
   __syncthreads();
-  for (; k < N; k += stride) {
+  for (; k < nsets; k += stride) {
     convert();                                        // raw(k) -> gy4
     transform();                                      // planes(k) -> vt
     __syncthreads();
