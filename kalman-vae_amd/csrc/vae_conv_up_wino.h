@@ -145,39 +145,37 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
 
   // this lane's tile inside a column set: frame fl (4x4: four frames per set), tile (ty, tx)
   const int fl = S == 8 ? 0 : (j >> 2), ty = S == 8 ? (j >> 2) : ((j >> 1) & 1), tx = S == 8 ? (j & 3) : (j & 1);
-  const int pbase = fl * Wd::FS + g * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx + (2 * (wv & 3)) * 4 * Wd::PLANE;   // k-steps 2 wv, 2 wv + 1 (waves 0-3)
-  const int vbase_w = ((2 * (wv & 3)) * 64 + lane) * K::VROW, vbase_r = lane * K::VROW;
+  const int pbase = fl * Wd::FS + g * Wd::PLANE + 2 * ty * Wd::RS + 2 * tx + wv * 4 * Wd::PLANE;   // k-step wv
+  const int vbase_w = (wv * 64 + lane) * K::VROW, vbase_r = lane * K::VROW;
   // ... and where its 4x4 block of the final [32, 2S, 2S] image goes: channel co0 / 4 + g, rows 4 ty.., columns 4 tx..
   const int obase = fl * D::YFRAME + (co0 / 4 + g) * 4 * D::PF + 4 * ty * 2 * S + 4 * tx;
   // staging: two 16-byte pieces of the column set per thread
-  // The shared work (staging, patch transform) is done by waves 0-3 alone: the SIMD's arbiter favours them, so they reach the
-  // barrier ~3000 cycles before their partners 4-7 anyway (stamps, tools/wino_stamp.hip); the partners only run MFMAs + epilogue.
-  const bool helper = wv < 4;
-  int sdst[2];
+  // The two waves of a SIMD (wv, wv + 4) run the interval in OPPOSITE order - waves 0-3: staging + patch transform, then MFMAs;
+  // waves 4-7: MFMAs first, the shared work last - so that one wave's VALU / LDS phase lies beside the other's MFMA phase
+  // (both in the same order: 11.3k cycles per column set; shared work on waves 0-3 only: 10.8k; stamps, tools/wino_stamp.hip).
+  const bool early = wv < 4;
+  int sdst[1];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int e = ((tid & 255) + 256 * q) * 4, f = e / D::XFRAME, ci = (e % D::XFRAME) / D::PF, pix = e % D::PF;
+  for (int q = 0; q < 1; ++q) {
+    const int e = (tid + 512 * q) * 4, f = e / D::XFRAME, ci = (e % D::XFRAME) / D::PF, pix = e % D::PF;
     sdst[q] = f * Wd::FS + ci * Wd::PLANE + (pix / S + 1) * Wd::RS + pix % S + 1;
   }
 
-  float4 pre[2];
+  float4 pre[1];
   auto fetch = [&](int64_t k) {
-    if (!helper) return;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) pre[q] = em_ld4(rx, (uint32_t)(k * K::CSG + ((tid & 255) + 256 * q) * 4) * 4u);
+    for (int q = 0; q < 1; ++q) pre[q] = em_ld4(rx, (uint32_t)(k * K::CSG + (tid + 512 * q) * 4) * 4u);
   };
   auto stage = [&](float *xw) {
-    if (!helper) return;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 1; ++q) {
       float *d = xw + sdst[q];
       d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
     }
   };
-  auto transform = [&](const float *xr, float *vw) {   // this wave's two k-steps of a column set
-    if (!helper) return;
+  auto transform = [&](const float *xr, float *vw) {   // this wave's k-step of a column set
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 1; ++h) {
       float2 d[4][2];
       float v[16];
       wino_patch_load(xr + pbase + h * 4 * Wd::PLANE, Wd::RS, d);
@@ -254,20 +252,34 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
   __syncthreads();
   for (int slot = 0; k < nsets; k += 2 * stride, ++slot) {
     WN_STAMP(slot, 0);
-    stage(xin);                                      // set n+2 (its buffer held set n, transformed one step ago)
-    fetch(k + 3 * stride);
-    transform(xin + K::CSX, vt + K::VSET);           // set n+1
+    if (early) {
+      stage(xin);                                    // set n+2 (its buffer held set n, transformed one step ago)
+      fetch(k + 3 * stride);
+      transform(xin + K::CSX, vt + K::VSET);         // set n+1
+    }
     WN_STAMP(slot, 1);
     compute(vt, k);                                  // set n
     WN_STAMP(slot, 2);
+    if (!early) {
+      stage(xin);
+      fetch(k + 3 * stride);
+      transform(xin + K::CSX, vt + K::VSET);
+    }
     __syncthreads();
     WN_STAMP(slot, 3);
-    stage(xin + K::CSX);
-    fetch(k + 4 * stride);
-    transform(xin, vt);
+    if (early) {
+      stage(xin + K::CSX);
+      fetch(k + 4 * stride);
+      transform(xin, vt);
+    }
     WN_STAMP(slot, 4);
     compute(vt + K::VSET, k + stride);
     WN_STAMP(slot, 5);
+    if (!early) {
+      stage(xin + K::CSX);
+      fetch(k + 4 * stride);
+      transform(xin, vt);
+    }
     __syncthreads();
     WN_STAMP(slot, 6);
   }
