@@ -225,7 +225,6 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
       float m[16];
 #pragma unroll
       for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
-      if (r == 0) WN_STAMP((int)((k - blockIdx.x) / stride / 2), 7);   // (second half overwrites the first: MFMAs done)
       wino_out(m, y[r]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) y[r][q] = fmaxf(y[r][q] + bv[r], 0.f);
