@@ -29,6 +29,8 @@ typedef float wn_f4 __attribute__((ext_vector_type(4)));
 #define WN_STAMP(slot, k) do {} while (0)
 #endif
 #define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// (Raising the issue priority of one wave per SIMD with s_setprio, to break a suspected lockstep of the two waves of a SIMD, was
+//  measured: 2 % on the kernels alone, -1.5 % on the training step, where the side-stream kernels then wait longer.)
 
 template <int S>
 struct WinoDims {
@@ -346,15 +348,19 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino(const float *__res
 
   // (the staging phases recompute their addresses from an opaque copy of tid: hoisted out of the loop they would sit in
   //  registers through the MFMA phase, which has none to spare)
-  auto dma = [&](int64_t k) {                         // eight 8 KB pieces: g_out then out of column set k
+  // eight 8 KB pieces per column set (g_out and out, four each).  Issued back to back they hold the later waves of the workgroup
+  // for ~3000 cycles (the memory queue is full: stamps, tools/wino_stamp_bwd.hip) before their first MFMA; dealt out one pair
+  // per k-step over the first four k-steps they queue behind the partner wave's MFMAs instead.
+  auto dma_piece = [&](int64_t k, int q) {
     int t2 = tid;
     asm volatile("" : "+v"(t2));
+    const uint32_t off = (uint32_t)(k * K::RAW + (t2 + 512 * q) * 4) * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(rawg + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+  };
+  auto dma = [&](int64_t k) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t off = (uint32_t)(k * K::RAW + (t2 + 512 * q) * 4) * 4u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(rawg + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q) dma_piece(k, q);
   };
   auto convert = [&]() {                              // raw -> masked, un-shuffled planes with zero borders (co = 4 c + 2 dy + dx)
     int t2 = tid;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino(const float *__res
       d[r][1] = *reinterpret_cast<const float2 *>(p + 2);
     }
   };
-  auto compute = [&]() {
+  auto compute = [&](int64_t knext) {
     wn_f4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
@@ -408,6 +414,8 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino(const float *__res
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < 16; ++p) acc[p] = WN_MFMA(U[p][s], v[p], acc[p]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < 4) dma_piece(knext, s);                 // the raw buffers are free since the convert phase
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[r][0] = dn[r][0], d[r][1] = dn[r][1];
@@ -426,15 +434,19 @@ __global__ __launch_bounds__(512) void k_dec_up_bwd_data_wino(const float *__res
   int64_t k = blockIdx.x;
   dma(k);
   __syncthreads();                                    // zero fill done, set k landed (the barrier's fence drains the DMA)
-  for (; k < nsets; k += stride) {
+  for (int slot = 0; k < nsets; k += stride, ++slot) {
+    WN_STAMP(slot, 0);
     convert();
     fold();                                           // previous set's four partial sums -> g_x
+    WN_STAMP(slot, 1);
     __syncthreads();
-    dma(k + stride);                                  // raw buffers are free again; lands behind the MFMAs
-    __builtin_amdgcn_sched_barrier(0);                // (issued HERE, not sunk to the end of the phase)
-    compute();
+    WN_STAMP(slot, 2);
+    WN_STAMP(slot, 3);
+    compute(k + stride);                              // ... and the next set's DMA, dealt out between its k-steps
     done = (uint32_t)(k * 2048) * 4u;
+    WN_STAMP(slot, 4);
     __syncthreads();
+    WN_STAMP(slot, 5);
   }
   fold();
 }
@@ -479,15 +491,16 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict
   for (int p = 0; p < 16; ++p) acc[p][0] = acc[p][1] = wn_f4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 
-  auto dma = [&](int64_t k) {
+  auto dma_piece = [&](int64_t k, int q) {            // dealt out one pair per k-step (see the data gradient)
     int t2 = tid;
     asm volatile("" : "+v"(t2));
+    const uint32_t off = (uint32_t)(k * K::RAW + (t2 + 512 * q) * 4) * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(rawg + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
+  };
+  auto dma = [&](int64_t k) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t off = (uint32_t)(k * K::RAW + (t2 + 512 * q) * 4) * 4u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void *)(rawg + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ro, (__attribute__((address_space(3))) void *)(rawo + (wv * 64 + 512 * q) * 4), 16, off, 0, 0, 0);
-    }
+    for (int q = 0; q < 4; ++q) dma_piece(k, q);
   };
   float4 pre;
   auto fetch = [&](int64_t k) {
@@ -538,7 +551,7 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4 *>(vt + t2 * K::VROW + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
   };
-  auto compute = [&]() {
+  auto compute = [&](int64_t knext) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       // A operands: (A gy A^T)_p of (co = 16 wv + j, tile g of the k-step); gy tile = (y00, y01, y10, y11)
@@ -569,6 +582,9 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict
           acc[4 * q + 3][nh] = WN_MFMA(yh[4 * q + 3], b[q].w, acc[4 * q + 3][nh]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      dma_piece(knext, ks);                           // raw buffers are free since the convert phase
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -583,11 +599,9 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict
     convert();                                        // raw(k) -> gy4
     transform();                                      // planes(k) -> vt
     __syncthreads();
-    dma(k + stride);
-    __builtin_amdgcn_sched_barrier(0);
     stage();                                          // planes <- x(k + stride)
     fetch(k + 2 * stride);
-    compute();
+    compute(k + stride);                              // ... and the DMA of raw(k + stride), dealt out between the k-steps
     __syncthreads();
   }
   // G^T Z G per (co, ci), partial sums of this workgroup
