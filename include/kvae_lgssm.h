@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 5
+#define KVAE_ABI_VERSION 6
 
 typedef enum {
   KVAE_OK = 0,
@@ -230,6 +230,10 @@ int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in,
 int64_t kvae_bias_partial_rows(int64_t N);
 /* out[c] = sum_r partials[r, c]: the second stage of the partial-row reductions above and below. */
 int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, void *stream);
+/* Two independent column sums in ONE launch (a layer's weight- and bias-gradient partials: the training step has eleven such
+ * pairs, and a launch of a few microseconds of work costs as much again in the stream). */
+int kvae_colsum2(const float *partials_a, float *out_a, int64_t rows_a, int64_t cols_a, const float *partials_b, float *out_b,
+                 int64_t rows_b, int64_t cols_b, void *stream);
 
 /* ---- fused Bernoulli reconstruction term of the frame VAE --------------------------------- */
 

@@ -461,7 +461,9 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
 
 int kvae_abi_version(void) { return KVAE_ABI_VERSION; }
 const char *kvae_last_error(void) { return g_err; }
-const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64, one wavefront per sequence) abi " "5"; }
+#define KVAE_STR2(x) #x
+#define KVAE_STR(x) KVAE_STR2(x)
+const char *kvae_build_info(void) { return "kvae_lgssm gfx950 (HIP, wave64) abi " KVAE_STR(KVAE_ABI_VERSION); }
 
 }  // extern "C"
 
@@ -518,11 +520,11 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
 // out[c] = sum_r partials[r, c]: second stage of every deterministic two-stage reduction (bias / weight gradient partial
 // rows).  HBM-bound (the 32->128 layers hand over 256 x 36864 floats = 38 MB): a lane owns four columns (dwordx4, 1 KiB per
 // wave and row), the eight waves of a block take every eighth row, four rows in flight per wave, fold through LDS.
-__global__ __launch_bounds__(512) void k_colsum_v4(const float *__restrict__ partials, float *__restrict__ out, int64_t rows,
-                                                   int64_t cols) {
+__device__ __forceinline__ void colsum_v4_body(const float *__restrict__ partials, float *__restrict__ out, int64_t rows, int64_t cols,
+                                               unsigned block) {
   __shared__ float4 red[8][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  const int64_t c = ((int64_t)block * 64 + lane) * 4;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   if (c < cols) {
     const float *p = partials + c;
@@ -549,6 +551,17 @@ __global__ __launch_bounds__(512) void k_colsum_v4(const float *__restrict__ par
     for (int w = 1; w < 8; ++w) { const float4 u = red[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
     *reinterpret_cast<float4 *>(out + c) = t;
   }
+}
+__global__ __launch_bounds__(512) void k_colsum_v4(const float *__restrict__ partials, float *__restrict__ out, int64_t rows,
+                                                   int64_t cols) {
+  colsum_v4_body(partials, out, rows, cols, blockIdx.x);
+}
+// two jobs in one launch: the first nb_a workgroups take job a, the rest job b
+__global__ __launch_bounds__(512) void k_colsum_v4_pair(const float *__restrict__ pa, float *__restrict__ oa, int64_t rows_a, int64_t cols_a,
+                                                        unsigned nb_a, const float *__restrict__ pb, float *__restrict__ ob,
+                                                        int64_t rows_b, int64_t cols_b) {
+  if (blockIdx.x < nb_a) colsum_v4_body(pa, oa, rows_a, cols_a, blockIdx.x);
+  else colsum_v4_body(pb, ob, rows_b, cols_b, blockIdx.x - nb_a);
 }
 // any column count (scalar): 64 columns x 4 row lanes per block
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partials, float *__restrict__ out, int64_t rows,
@@ -703,6 +716,18 @@ int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, v
   else
     k_colsum<<<dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(partials, out, rows, cols);
   return launch_status("k_colsum");
+}
+int kvae_colsum2(const float *pa, float *oa, int64_t rows_a, int64_t cols_a, const float *pb, float *ob, int64_t rows_b,
+                 int64_t cols_b, void *stream) {
+  if (!pa || !oa || !pb || !ob) return KVAE_ERR_NULL;
+  if (rows_a < 1 || cols_a < 1 || rows_b < 1 || cols_b < 1) return KVAE_ERR_ARG;
+  if (((cols_a | cols_b) & 3) == 0 && ((((uintptr_t)pa | (uintptr_t)oa | (uintptr_t)pb | (uintptr_t)ob) & 15) == 0)) {
+    const unsigned nb_a = (unsigned)((cols_a + 255) / 256), nb_b = (unsigned)((cols_b + 255) / 256);
+    k_colsum_v4_pair<<<dim3(nb_a + nb_b), dim3(512), 0, (hipStream_t)stream>>>(pa, oa, rows_a, cols_a, nb_a, pb, ob, rows_b, cols_b);
+    return launch_status("k_colsum_v4_pair");
+  }
+  const int rc = kvae_colsum(pa, oa, rows_a, cols_a, stream);
+  return rc ? rc : kvae_colsum(pb, ob, rows_b, cols_b, stream);
 }
 int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHUNK - 1) / KVAE_EPI_SAMPLES_PER_CHUNK; }
 }  // extern "C"

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -47,7 +47,7 @@ class InputGrads(C.Structure):  # kvae_lgssm_input_grads
 
 SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_alpha_lstm_bwd", "kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
            "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_lstm_fwd",
-           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
+           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_colsum2", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
            "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows",
@@ -147,6 +147,8 @@ class LgssmLib:
         d.kvae_conv_edge_partial_rows.restype = C.c_int64
         d.kvae_colsum.argtypes = [vp, vp, C.c_int64, C.c_int64, vp]
         d.kvae_colsum.restype = C.c_int
+        d.kvae_colsum2.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp]
+        d.kvae_colsum2.restype = C.c_int
         d.kvae_bias_partial_rows.argtypes = [C.c_int64]
         d.kvae_bias_partial_rows.restype = C.c_int64
         d.kvae_abi_version.restype = C.c_int
@@ -246,6 +248,21 @@ def _colsum_raw(p2):
     lib = lib_for(p2)
     lib.check(lib.dll.kvae_colsum(ptr(p2), ptr(out), p2.shape[0], p2.shape[1], stream_for(p2)), "kvae_colsum")
     return out
+
+
+def colsum_pair(a, b):
+    """(colsum(a), colsum(b)) in one launch when neither needs the two-pass folding of tall inputs (k_colsum_v4_pair): the
+    weight- and bias-gradient partials of one layer."""
+    import torch
+    a2, b2 = a.reshape(a.shape[0], -1).contiguous(), b.reshape(b.shape[0], -1).contiguous()
+    if any(p.shape[0] >= 1024 and p.shape[1] < 4096 for p in (a2, b2)) or a2.device != b2.device:
+        return colsum(a), colsum(b)
+    oa = torch.empty(a2.shape[1], device=a2.device, dtype=torch.float32)
+    ob = torch.empty(b2.shape[1], device=b2.device, dtype=torch.float32)
+    lib = lib_for(a2)
+    lib.check(lib.dll.kvae_colsum2(ptr(a2), ptr(oa), a2.shape[0], a2.shape[1], ptr(b2), ptr(ob), b2.shape[0], b2.shape[1],
+                                   stream_for(a2)), "kvae_colsum2")
+    return oa.view(a.shape[1:]), ob.view(b.shape[1:])
 
 
 def colsum(partials):

@@ -12,6 +12,7 @@ from .. import _native as N
 
 
 colsum = N.colsum
+colsum_pair = N.colsum_pair
 
 
 def _chunks(n, size):
@@ -97,7 +98,8 @@ class DecoderHead(torch.autograd.Function):
         lib.check(lib.dll.kvae_dec_head_bwd(N.ptr(h), N.ptr(weight), N.ptr(g), N.ptr(g_h) if g_h is not None else None,
                                             N.ptr(wp), N.ptr(bp), N.ptr(scratch), Nb, Cin, s, N.stream_for(h)),
                   "kvae_dec_head_bwd")
-        return g_h, colsum(wp).view_as(weight), colsum(bp)
+        gw, gb = colsum_pair(wp, bp)
+        return g_h, gw.view_as(weight), gb
 
 
 class EncoderStem(torch.autograd.Function):
@@ -134,7 +136,8 @@ class EncoderStem(torch.autograd.Function):
         bp = torch.empty(rows, Cout, device=x.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(g), N.ptr(wp), N.ptr(bp), Nb, Cout, x.shape[2],
                                             N.stream_for(x)), "kvae_enc_stem_bwd")
-        return None, colsum(wp).view(ctx.wshape), colsum(bp)
+        gw, gb = colsum_pair(wp, bp)
+        return None, gw.view(ctx.wshape), gb
 
 
 class EncoderMid(torch.autograd.Function):
@@ -176,7 +179,8 @@ class EncoderMid(torch.autograd.Function):
             lib.check(lib.dll.kvae_enc_mid_bwd(N.ptr(x[a:b]), N.ptr(weight), N.ptr(out[a:b]), N.ptr(g[a:b]),
                                                N.ptr(g_x[a:b]) if g_x is not None else None, N.ptr(wp), N.ptr(bp), b - a, Cc, s,
                                                N.stream_for(x)), "kvae_enc_mid_bwd")
-            gw, gb = _acc(gw, colsum(wp)), _acc(gb, colsum(bp))
+            cw, cb = colsum_pair(wp, bp)
+            gw, gb = _acc(gw, cw), _acc(gb, cb)
         return g_x, gw.view_as(weight), gb
 
 
@@ -220,7 +224,8 @@ class DecoderUp(torch.autograd.Function):
             lib.check(N.timed(f"dec_up_bwd_s{s}", x, lambda: lib.dll.kvae_dec_up_bwd(
                 N.ptr(x[a:b]), N.ptr(weight), N.ptr(out[a:b]), N.ptr(g[a:b]), N.ptr(g_x[a:b]) if g_x is not None else None, N.ptr(wp),
                 N.ptr(bp), b - a, Cin, s, N.stream_for(x))), "kvae_dec_up_bwd")
-            gw, gb = _acc(gw, colsum(wp)), _acc(gb, colsum(bp))
+            cw, cb = colsum_pair(wp, bp)
+            gw, gb = _acc(gw, cw), _acc(gb, cb)
         return g_x, gw.view_as(weight), gb
 
 
@@ -265,7 +270,8 @@ class EncoderHead(torch.autograd.Function):
         lib.check(lib.dll.kvae_enc_head_bwd(N.ptr(feat), N.ptr(w_mu), N.ptr(w_var), N.ptr(var), _optr(eps), _optr(g_a), _optr(g_mu),
                                             _optr(g_var), N.ptr(g_feat), N.ptr(wp), N.ptr(bp), Nb, 512, 2, ctx.ne,
                                             N.stream_for(feat)), "kvae_enc_head_bwd")
-        gw, gb = colsum(wp).view(2, 2, 512), colsum(bp).view(2, 2)
+        gw, gb = colsum_pair(wp, bp)
+        gw, gb = gw.view(2, 2, 512), gb.view(2, 2)
         return g_feat, gw[0], gb[0], gw[1], gb[1], None, None
 
 
@@ -299,7 +305,8 @@ class DecoderFc(torch.autograd.Function):
         bp = torch.empty(rows, 512, device=a.device, dtype=torch.float32)
         lib.check(lib.dll.kvae_dec_fc_bwd(N.ptr(g), N.ptr(a), N.ptr(weight), N.ptr(g_a), N.ptr(wp), N.ptr(bp), Nb, 512, 2,
                                           N.stream_for(a)), "kvae_dec_fc_bwd")
-        return g_a, colsum(wp).view(512, 2), colsum(bp)
+        gw, gb = colsum_pair(wp, bp)
+        return g_a, gw.view(512, 2), gb
 
 
 class LatentReg(torch.autograd.Function):

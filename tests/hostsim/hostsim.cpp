@@ -227,6 +227,11 @@ int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, v
   }
   return KVAE_OK;
 }
+int kvae_colsum2(const float *pa, float *oa, int64_t rows_a, int64_t cols_a, const float *pb, float *ob, int64_t rows_b,
+                 int64_t cols_b, void *s) {
+  const int rc = kvae_colsum(pa, oa, rows_a, cols_a, s);
+  return rc ? rc : kvae_colsum(pb, ob, rows_b, cols_b, s);
+}
 int kvae_bias_shuffle_act_bwd(const float *g_out, const float *out, float *g_in, float *bias_partials, int64_t N, int32_t C,
                               int32_t H, int32_t W, int32_t r, int32_t relu, void *) {
   if (!g_out || !g_in || (relu && !out)) return KVAE_ERR_NULL;
