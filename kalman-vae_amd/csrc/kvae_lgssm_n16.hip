@@ -72,14 +72,45 @@ __global__ __launch_bounds__(64) void k_elbo_n16(kvae_lgssm_problem P, const flo
   n16::elbo_main<GRADS, HAS_GQ>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t, L);
 }
 
+// shared Q: four steps per wavefront (lgssm_n16_elbo.h, elbo_probe4 / elbo_main4); grid = B * ceil(T / 4)
+__global__ __launch_bounds__(64) void k_elbo_probe4_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
+                                                        float *zst, int32_t *levels) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
+  n16::elbo_probe4(P, Sig_s, mus, eps, zst, levels, b, t0, w == 0 && P.T >= 2);
+}
+template <bool GRADS>
+__global__ __launch_bounds__(64) void k_elbo4_n16(kvae_lgssm_problem P, const float *mus, const float *Sigs, const float *eps,
+                                                  float *terms, const int32_t *levels, const float *zst, float *g_mus,
+                                                  float *g_Sigs, kvae_lgssm_input_grads G) {
+  __shared__ n16::ELds4 L;
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
+  n16::elbo_main4<GRADS>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t0, L);
+}
+static bool elbo_shared_q(const kvae_lgssm_problem *p) {
+  static const int env = getenv("KVAE_ELBO4") ? atoi(getenv("KVAE_ELBO4")) : 1;   // 0: one step per wavefront (A/B runs)
+  return env != 0 && p->Q.sb == 0 && p->Q.st == 0;
+}
+
 extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
                                            float *zst, int32_t *levels, hipStream_t s) {
+  if (elbo_shared_q(p)) {
+    k_elbo_probe4_n16<<<dim3((unsigned)((int64_t)p->B * ((p->T + 3) / 4))), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
+    return;
+  }
   k_elbo_probe_n16<<<dim3((unsigned)((int64_t)p->B * p->T)), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
 }
 extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
                                      float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
                                      const kvae_lgssm_input_grads *g, int have_g, hipStream_t s) {
   const dim3 grid((unsigned)((int64_t)p->B * p->T)), block(64);
+  if (elbo_shared_q(p) && !(have_g && g->gQ.ptr)) {
+    const dim3 grid4((unsigned)((int64_t)p->B * ((p->T + 3) / 4)));
+    if (have_g) k_elbo4_n16<true><<<grid4, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
+    else k_elbo4_n16<false><<<grid4, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
+    return;
+  }
   if (!have_g) k_elbo_n16<false, false><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
   else if (g->gQ.ptr) k_elbo_n16<true, true><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
   else k_elbo_n16<true, false><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);

@@ -94,7 +94,10 @@ __device__ __forceinline__ void inv_cols(const Chol &c, float (&y)[N]) {
 }
 template <int K>
 __device__ __forceinline__ void inv_step(const Chol &c, float (&y)[N]) {
-  asm volatile("s_nop 1");                         // y[C] of the previous step -> DPP read
+  // y[C] of the previous step (or the identity just selected into it) -> DPP read: the wait states must sit AFTER those writes,
+  // so the guard names the registers (an operand-less s_nop let hipcc sink the initialisation of y[0] below it)
+  asm volatile("s_nop 1" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]), "+v"(y[8]),
+               "+v"(y[9]), "+v"(y[10]), "+v"(y[11]), "+v"(y[12]), "+v"(y[13]), "+v"(y[14]), "+v"(y[15]));
   inv_cols<K, 0>(c, y);
   if constexpr (K + 2 < N) inv_step<K + 1>(c, y);
 }
@@ -309,6 +312,211 @@ __device__ __forceinline__ void elbo_main(const kvae_lgssm_problem &P, const flo
       const f4 Qi = mtn(Xq, Xq);
       const f4 gq = has_prev ? 0.5f * (vtW * vtL - Qi) : zero4();
       store_c(gstack_at(G.gQ, b, t), gq, i, g);
+    }
+  }
+}
+
+// ---- shared Q (lstm dynamics: Q is one matrix for the whole batch): FOUR STEPS per wavefront ---------------------------------
+// With a shared Q three of the four row-groups of elbo_probe / elbo_main factorise the same matrix again in every wavefront, or
+// idle.  Here group g works on step t0 + g: the launch has a quarter of the wavefronts, and the kernels are bound by VALU
+// issue.  Q is factorised once per wavefront (all groups, redundantly: X = L_Q^-1 and X^T with their rows on the lanes, so that
+// v = Q^-1 d is two 16-FMA mat-vecs and the quadratic form is |X d|^2 exactly as torch's MultivariateNormal computes it);
+// v_{t+1} is recomputed by the group of step t (its A_{t+1}, B_{t+1} rows come from L1 / L2: the neighbouring group reads the
+// same lines); the Cholesky backward runs its two MFMA products once per group.
+struct alignas(16) ELds4 {
+  float lt[4][N * LD];   // L of every group's Sigma_s (rows-on-lanes -> C-layout); first used to transpose L_Q^-1
+  float xt[4][N * LD];   // L^-1
+  float gz[4][N];        // d ELBO / d z_t of every group
+  Lds s;
+};
+
+__device__ __forceinline__ void elbo_probe4(const kvae_lgssm_problem &P, const float *Sig_s, const float *mus, const float *eps,
+                                            float *zst, int32_t *levels, int b, int t0, bool probe_q) {
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int t = t0 + g;
+  const bool valid = t < P.T;
+  const int64_t q = (int64_t)b * P.T + (valid ? t : P.T - 1);
+  float m0[N], m[N];
+  load_sym_rows(Sig_s + q * NN, m0, i, 0.0f, false);
+  int lv = 5;
+  bool done = false;
+  for (int level = 0; level < 5; ++level) {
+    const float jit = jitter_of_level(level);
+#pragma unroll
+    for (int k = 0; k < N; ++k) m[k] = valid ? m0[k] + (k == i ? jit : 0.0f) : (k == i ? 1.0f : 0.0f);
+    Chol c;
+    cholesky_rows(m, c, i);
+    if (level == 0 && valid && !c.bad) {   // z_t of level 0 for the main launch
+      float epsL = eps[q * N + i];
+      float acc = mus[q * N + i];
+      dpp_guard(epsL);
+      lower_matvec_acc<0>(acc, c, epsL, i);
+      zst[q * N + i] = acc;
+    }
+    if (!done && !c.bad) lv = level, done = true;
+    if (!__any(!done)) break;
+  }
+  if (i == 0 && valid && lv > 0) atomic_max_i32(levels + 0, lv);
+  if (probe_q) {                           // one wavefront of the launch: the ladder of the shared Q
+    load_sym_rows(P.Q.ptr, m0, i, 0.0f, false);
+    int lq = 5;
+    for (int level = 0; level < 5; ++level) {
+      const float jit = jitter_of_level(level);
+#pragma unroll
+      for (int k = 0; k < N; ++k) m[k] = m0[k] + (k == i ? jit : 0.0f);
+      Chol c;
+      cholesky_rows(m, c, i);
+      if (!c.bad) { lq = level; break; }   // the four groups hold the same matrix: uniform
+    }
+    if (lane == 0 && lq > 0) atomic_max_i32(levels + 1, lq);
+  }
+}
+
+// acc += sum_k row[k] * (lane k of vL's row)
+__device__ __forceinline__ float matvec_reg(const float (&row)[N], float vL) {
+  float acc = 0.0f;
+  dpp_guard(vL);
+  matvec_rows_acc<0>(acc, row, vL);
+  return acc;
+}
+// column i of a row-major 16x16 matrix (row i of its transpose)
+__device__ __forceinline__ void load_col(const float *M, float (&col)[N], int i) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) col[k] = M[k * N + i];
+}
+
+template <bool GRADS>
+__device__ __forceinline__ void elbo_main4(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps,
+                                           float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
+                                           const kvae_lgssm_input_grads &G, int b, int t0, ELds4 &L) {
+  if (levels[0] != 0 || levels[1] != 0) return;   // jittered batch: the generic kernel computes this call
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, T = P.T;
+  const int tr = t0 + g;
+  const bool valid = tr < T;
+  const int t = valid ? tr : T - 1;                // clamped: invalid groups recompute the last step and store nothing
+  const int64_t bT = (int64_t)b * T, q = bT + t;
+  const bool has_prev = t >= 1, has_next = t + 1 < T;
+  // ---- the shared Q: X = (chol(Q + 1e-6 I))^-1 and X^T, rows on lanes; log-determinant ----
+  float xq[N], xqt[N], logdetQ;
+  {
+    float mq[N];
+    load_sym_rows(P.Q.ptr, mq, i, 1e-6f, false);
+    Chol cq;
+    cholesky_rows(mq, cq, i);
+    inverse_rows(cq, xq, i);
+    logdetQ = row_sum(__logf(cq.ld));
+    __syncthreads();
+    rows_to_tile(xq, L.lt[g], i);                  // upper triangle cleared: X is lower triangular
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) xqt[k] = L.lt[g][k * LD + i];
+#pragma unroll
+    for (int k = 0; k < N; ++k) xq[k] = k <= i ? xq[k] : 0.0f;
+  }
+  // ---- Sigma_s[t] of this group ----
+  float m[N];
+  load_sym_rows(Sigs + q * NN, m, i, 1e-6f, false);
+  Chol c;
+  cholesky_rows(m, c, i);
+  const float zt = zst[q * N + i];
+  const float zp = has_prev ? zst[(q - 1) * N + i] : 0.0f, zn = has_next ? zst[(q + 1) * N + i] : 0.0f;
+  // entropy: log N(z_t; mu_s, L L^T)
+  float y = zt - mus[q * N + i];
+  fsub_step<0>(c, y);
+  const float xf = y * c.rinv;
+  const float gaussS = -0.5f * (N * KV_LOG2PI + row_sum(xf * xf)) - row_sum(__logf(c.ld));
+  // transition into t: d_t = z_t - A_t z_{t-1} - B_t u_t, w = X d, v_t = X^T w
+  const float Az = matvec_rows(stack_at(P.A, b, t), zp, i);
+  const float Bu = matvec_rows(stack_at(P.Bm, b, t), P.U[q * N + i], i);
+  const float dt = has_prev ? zt - (Az + Bu) : 0.0f;
+  const float wt = matvec_reg(xq, dt);
+  const float gaussT = -0.5f * (N * KV_LOG2PI + row_sum(wt * wt)) - logdetQ;
+  // emission (p = 2): e = y - C z, R factorised without jitter
+  const float *C = stack_at(P.C, b, t);
+  const float Cl0 = C[i], Cl1 = C[N + i];
+  const float e0 = P.Y[q * 2] - row_sum(Cl0 * zt), e1 = P.Y[q * 2 + 1] - row_sum(Cl1 * zt);
+  const float l00 = __builtin_amdgcn_sqrtf(P.R[0]), l10 = P.R[2] / l00, l11 = __builtin_amdgcn_sqrtf(P.R[3] - l10 * l10);
+  const float w0 = e0 / l00, w1 = (e1 - l10 * w0) / l11;
+  const float qe1 = w1 / l11, qe0 = (w0 - l10 * qe1) / l00;      // R^{-1} e
+  const float mkr = *mask_addr(P, b, t);
+  const float mk = P.mask ? mkr : 1.0f;
+  // init (the wavefront that holds t = 0): log N(z_0; mu0, Sigma0), Sigma0 factorised as MultivariateNormal does (no jitter)
+  float gaussI = 0.0f, viL = 0.0f;
+  if (t0 == 0) {
+    float m0[N];
+    load_sym_rows(P.Sigma0 + (int64_t)b * P.Sigma0_sb, m0, i, 0.0f, true);
+    Chol c0;
+    cholesky_rows(m0, c0, i);
+    float y0 = zst[bT * N + i] - P.mu0[(int64_t)b * P.mu0_sb + i];
+    fsub_step<0>(c0, y0);
+    const float x0 = y0 * c0.rinv;
+    gaussI = -0.5f * (N * KV_LOG2PI + row_sum(x0 * x0)) - row_sum(__logf(c0.ld));
+    float v0 = x0 * c0.rinv;
+    bsub_step<N - 1>(c0, v0, i);
+    viL = t == 0 ? v0 : 0.0f;                       // every group computed step 0's; only its own group uses it
+  }
+  if (i == 0 && valid) {
+    terms[q * 4 + 0] = has_prev ? gaussT : 0.0f;
+    terms[q * 4 + 1] = mk * (-0.5f * (2 * KV_LOG2PI + (w0 * w0 + w1 * w1)) - (__logf(l00) + __logf(l11)));
+    terms[q * 4 + 2] = t == 0 ? gaussI : 0.0f;
+    terms[q * 4 + 3] = -gaussS;
+  }
+  if constexpr (GRADS) {
+    const float vt = matvec_reg(xqt, wt);                         // Q^-1 d_t (0 at t = 0)
+    // v_{t+1}, recomputed here (the next group / wavefront computes it as its own v_t)
+    const float *An = stack_at(P.A, b, has_next ? t + 1 : t), *Bn = stack_at(P.Bm, b, has_next ? t + 1 : t);
+    const float Azn = matvec_rows(An, zt, i);
+    const float Bun = matvec_rows(Bn, P.U[(q + (has_next ? 1 : 0)) * N + i], i);
+    const float dn = has_next ? zn - (Azn + Bun) : 0.0f;
+    const float vn = matvec_reg(xqt, matvec_reg(xq, dn));
+    // gz_t = -v_t + A_{t+1}^T v_{t+1} + mask C^T R^{-1} e - Sigma0^{-1}(z_0 - mu0)
+    float col[N];
+    load_col(An, col, i);
+    const float gz = -vt + matvec_reg(col, vn) + mk * (Cl0 * qe0 + Cl1 * qe1) - viL;
+    if (valid) {
+      g_mus[q * N + i] = gz;
+      float *gC = gstack_at(G.gC, b, t);
+      gC[i] = mk * qe0 * zt, gC[N + i] = mk * qe1 * zt;
+      if (i < 2) G.gY[q * 2 + i] = -mk * (i ? qe1 : qe0);
+      // gA_t = v_t z_{t-1}^T, gB_t = v_t u_t^T: row i on lane i
+      float *gA = gstack_at(G.gA, b, t) + i * N, *gB = gstack_at(G.gB, b, t) + i * N;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const f4 zq = has_prev ? load_w(zst + (q - 1) * N, k4) : zero4();
+        *reinterpret_cast<f4 *>(gA + 4 * k4) = vt * zq;
+        *reinterpret_cast<f4 *>(gB + 4 * k4) = vt * load_w(P.U + q * N, k4);
+      }
+      if (G.gU) {
+        load_col(stack_at(P.Bm, b, t), col, i);
+        G.gU[q * N + i] = matvec_reg(col, vt);                    // B_t^T v_t
+      }
+    }
+    // ---- Cholesky backward into Sigma_s of every group: sym(L^-T Phi L^-1) on the matrix cores, one group after the other ----
+    float xr[N];
+    inverse_rows(c, xr, i);
+    __syncthreads();
+    rows_to_tile(c.l, L.lt[g], i);
+    rows_to_tile(xr, L.xt[g], i);
+    L.gz[g][i] = gz;
+    __syncthreads();
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      if (t0 + gg >= T) break;                                    // wave-uniform
+      const int64_t qg = bT + t0 + gg;
+      const f4 Lc = tile_c(L.lt[gg], i, g);                       // C-layout of L_s
+      const float aL = mtv(Lc, load_w(L.gz[gg], g));              // a = L^T gz
+      const f4 Xs = tile_c(L.xt[gg], i, g);
+      const f4 epsW = load_w(eps + qg * N, g);
+      const float epsL = eps[qg * N + i];
+      f4 Pht;                                                      // C-layout of Phi^T: [4g+r][i] = Phi[i][4g+r]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = 4 * g + r;
+        Pht[r] = cc < i ? aL * epsW[r] : (cc == i ? 0.5f * (aL * epsL + 1.0f) : 0.0f);
+      }
+      const f4 PX = mtn(Pht, Xs);                                  // Phi L^{-1}
+      const f4 S = mtn(Xs, PX);                                    // L^{-T} Phi L^{-1}
+      store_rows(g_Sigs + qg * NN, symmetrise(S, L.s, i, g), i, g);
     }
   }
 }
