@@ -18,16 +18,20 @@ def _random_problem(B, T, n, m, p, K, seed, device):
     return [t.to(device) for t in (A, Bm, Cm, alpha, Y, U, mask, eps)]
 
 
-def vs_oracle_random(DEV, B, T, n, m, p, K):
+def vs_oracle_random(DEV, B, T, n, m, p, K, dense_q=False):
     """HIP path vs the CPU oracle (C restatement for values, torch oracle autograd for gradients) on seeded
     inputs, incl. BASELINE configs[1] (B=256,T=50,n=4) and a configs[4] shard slice (n=16,T=200); ragged
-    sizes, masks, controls, T=1 and run-time dimensions."""
+    sizes, masks, controls, T=1 and run-time dimensions.  dense_q: a full SPD process noise shared by the batch (the default
+    0.02 I cannot tell a factor from its transpose - the n = 16 ELBO keeps chol(Q)^-1 AND its transpose on the lanes)."""
     from kvae.kalman.lgssm_ops import LgssmElbo, LgssmSmooth, mix_dynamics
     from oracle import c_oracle
     from oracle import torch_oracle as O
     A, Bm, Cm, alpha, Y, U, mask, eps = _random_problem(B, T, n, m, p, K, 100 + B + T, DEV)
     R = 0.03 * torch.eye(p, device=DEV)
     Q = 0.02 * torch.eye(n, device=DEV)
+    if dense_q:
+        Wq = torch.randn(n, n, generator=torch.Generator().manual_seed(7)).to(DEV)
+        Q = Q + 0.004 * (Wq @ Wq.T)
     mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)
     leaves = [t.clone().requires_grad_(True) for t in (A, Bm, Cm, alpha, Y, U)]
     rec, offs, (As, Bs, Cs) = mix_dynamics(leaves[3], leaves[:3])

@@ -116,6 +116,13 @@ def test_vs_oracle_random(B, T, n, m, p, K):
     parity_cases.vs_oracle_random(DEV, B, T, n, m, p, K)
 
 
+@pytest.mark.parametrize("B,T,n", [(3, 10, 16), (2, 7, 16), (5, 9, 4)])
+def test_vs_oracle_dense_shared_q(B, T, n):
+    """A full SPD process noise, T not a multiple of four: the four-steps-per-wavefront ELBO of the (16,16,2) kernels (ragged last
+    wavefront, chol(Q)^-1 and its transpose) and the n = 4 kernels, values and gradients."""
+    parity_cases.vs_oracle_random(DEV, B, T, n, n, 2, 2, dense_q=True)
+
+
 def test_n16_generic_fallback():
     parity_cases.n16_generic_fallback(DEV)
 
