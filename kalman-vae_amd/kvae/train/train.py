@@ -200,10 +200,12 @@ class Trainer:
                 self._forward_backward(self.static_x, self.static_mask)
                 self._clip_and_update()
         else:
-            with torch.cuda.graph(self.graph_fb):
+            # RCCL's watchdog thread polls events while this thread captures: "thread_local" keeps its calls from invalidating
+            # the capture (the default mode forbids CUDA/HIP calls from ANY thread of the process during capture)
+            with torch.cuda.graph(self.graph_fb, capture_error_mode="thread_local"):
                 self._forward_backward(self.static_x, self.static_mask)
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph_fb.pool(), capture_error_mode="thread_local"):
                 self._clip_and_update()
 
 

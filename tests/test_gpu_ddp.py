@@ -58,3 +58,59 @@ def test_two_ranks_graph_split_on_one_gpu():
     import numpy as np
     assert np.array_equal(res[0][1], res[1][1]), "replicas diverged after 4 steps"
     assert all(np.isfinite(r[2]) for r in res)
+
+
+def _rccl_worker(port, q):
+    """One rank, backend 'nccl' (RCCL): the multi-rank code path of Trainer - count-weighted flat buffer, forward+backward graph,
+    EAGER RCCL all-reduce, clip+Adam graph - with a real RCCL communicator (and its watchdog thread) alive during capture."""
+    for p in (str(ROOT), str(ROOT / "kalman-vae_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from kvae import noise
+    from kvae.model.model import KVAE
+    from kvae.train.synthetic import bouncing_ball
+    from kvae.train.train import Trainer
+    from kvae.utils.config import KVAEConfig
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    x = bouncing_ball(16, 12, 1234).float().cuda()
+    g = torch.Generator().manual_seed(5)
+    nz = dict(eps_a=torch.randn(16 * 12, 2, generator=g).cuda(), eps_z=torch.randn(16, 12, 4, generator=g).cuda())
+    res = []
+    for world_arg in (2, 1):          # 2: graph cut around the (one-rank) RCCL all-reduce; 1: the single-graph step
+        torch.manual_seed(0)
+        model = KVAE(KVAEConfig(dynamics_model="lstm", num_modes=3)).cuda().train()
+        model.beta = 1.0
+        tr = Trainer(model, use_graph=True, world_size=world_arg)
+        with noise.inject(**nz):
+            for _ in range(4):
+                out = tr.step(x)
+        torch.cuda.synchronize()
+        res.append((torch.cat([p.detach().flatten() for p in model.parameters()]).cpu().numpy(), float(out["loss"]),
+                    tr.graph_opt is not None))
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_graph_with_a_real_rccl_communicator():
+    """RCCL itself cannot be exercised with two ranks on the one GPU of the test box; one rank can: the collective is a
+    single-rank sum, everything around it (communicator + watchdog thread alive while the two graphs are captured with
+    capture_error_mode='thread_local', eager all-reduce between their replays) is what every rank of the 8-GPU run executes.
+    The result must equal the single-graph trainer's on the same noise."""
+    import numpy as np
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    (p2, l2, split2), (p1, l1, split1) = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert split2 and not split1
+    assert np.isfinite(l2) and abs(l2 - l1) <= 1e-4 * abs(l1)
+    assert float(np.abs(p2 - p1).max()) < 2e-4
