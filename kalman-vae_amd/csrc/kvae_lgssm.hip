@@ -978,8 +978,11 @@ int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *ou
   if (dec_up_wino()) {   // pairs of workgroups (one per half of the output channels) walk the column sets together
     const int64_t sets = side == 8 ? N : (N + 3) / 4;
     const dim3 wgrid((unsigned)(sets < 256 ? sets : 256));
-    if (side == 8) k_dec_up_fwd_wino<8><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
-    else k_dec_up_fwd_wino<4><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    static const int pm = getenv("KVAE_WINO_PM") ? atoi(getenv("KVAE_WINO_PM")) : 1;   // 0: k-step-major MFMA order (A/B runs)
+    if (side == 8 && pm) k_dec_up_fwd_wino<8, true><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    else if (side == 8) k_dec_up_fwd_wino<8, false><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    else if (pm) k_dec_up_fwd_wino<4, true><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    else k_dec_up_fwd_wino<4, false><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
     return launch_status("k_dec_up_fwd_wino");
   }
   if (side == 8) k_dec_up_fwd<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, N);

@@ -116,7 +116,7 @@ struct WinoFwd {
   static constexpr int VROW = 20, VSET = 8 * 64 * VROW;
 };
 
-template <int S>
+template <int S, bool PM>
 __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict__ x, const float *__restrict__ W,
                                                          const float *__restrict__ bias, float *__restrict__ out, int64_t N) {
   using D = UpDims<S>;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
         *reinterpret_cast<float4 *>(vw + vbase_w + h * 64 * K::VROW + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
   };
-  auto compute = [&](const float *vr, int64_t k) {     // 128 MFMAs + output transform, bias, shuffle, ReLU of column set k
+  auto compute_k = [&](const float *vr, int64_t k) {     // 128 MFMAs + output transform, bias, shuffle, ReLU of column set k
     wn_f4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
@@ -240,6 +240,74 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
       }
   };
 
+  // 128 MFMAs + output transform, bias, shuffle, ReLU of column set k.  POINT-major: the eight k-steps of a pair of points run
+  // back to back on two accumulators (alternating: the 40-cycle dependent latency of the 16x16x4 MFMA is covered), and a finished
+  // pair is folded into the 16 outputs (A^T . A is linear: y += its share) while the next pair is on the matrix core.  Eight live
+  // accumulator registers instead of 64, and the wave's vector work is spread under its own MFMAs instead of following them in
+  // a block that the partner wave of the SIMD can only partly cover (k-step-major: 11.3 k cycles per column set, stamps).
+  auto compute_p = [&](const float *vr, int64_t k) {
+    float y[4][4];                                   // [r][2a + b]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[r][q] = 0.f;
+    float2 bq[8], bn[8];                             // B operands of the pair (4u + 2h, 4u + 2h + 1), all eight k-steps
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bq[s] = *reinterpret_cast<const float2 *>(vr + vbase_r + s * 64 * K::VROW);
+    float sb[4][2];                                  // per output sub-pixel r: sum_v A^T[b][v] M[u][v] of the current row u
+    wn_f4 p0 = wn_f4{0.f, 0.f, 0.f, 0.f}, p1 = p0;   // the finished pair that is being folded
+    // fold of pair pq = (u, h), sub-pixel r.  A^T = (1 1 1 0 / 0 1 -1 -1): columns v = 0, 1 (h = 0) or 2, 3 (h = 1) of row u;
+    // with the row complete (h = 1): y[a][b] += A^T[a][u] s_b
+    auto fold = [&](int pq, int r) {
+      const int u = pq >> 1, h = pq & 1;
+      if (h == 0) sb[r][0] = p0[r] + p1[r], sb[r][1] = p1[r];
+      else {
+        sb[r][0] += p0[r], sb[r][1] -= p0[r] + p1[r];
+        if (u == 0) y[r][0] += sb[r][0], y[r][1] += sb[r][1];
+        if (u == 1) y[r][0] += sb[r][0], y[r][1] += sb[r][1], y[r][2] += sb[r][0], y[r][3] += sb[r][1];
+        if (u == 2) y[r][0] += sb[r][0], y[r][1] += sb[r][1], y[r][2] -= sb[r][0], y[r][3] -= sb[r][1];
+        if (u == 3) y[r][2] -= sb[r][0], y[r][3] -= sb[r][1];
+      }
+      // computed HERE: LLVM otherwise sinks these adds (their results are only read after the last MFMA) below every barrier
+      asm volatile("" : "+v"(sb[r][0]), "+v"(sb[r][1]), "+v"(y[r][0]), "+v"(y[r][1]), "+v"(y[r][2]), "+v"(y[r][3]));
+    };
+    // Hand-placed order, pinned group by group (left alone hipcc issues all 128 MFMAs first and the folds in one block after
+    // them): two MFMAs (one per chain), one operand read of the next pair, the fold of one sub-pixel of the previous pair every
+    // other group - ~4 vector instructions in a 64-cycle MFMA gap.
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      wn_f4 a0 = wn_f4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        a0 = WN_MFMA(U[2 * pp][s], bq[s].x, a0);
+        a1 = WN_MFMA(U[2 * pp + 1][s], bq[s].y, a1);
+        if (pp + 1 < 8) bn[s] = *reinterpret_cast<const float2 *>(vr + vbase_r + s * 64 * K::VROW + 2 * (pp + 1));
+        if (pp > 0 && (s & 1)) fold(pp - 1, s >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      p0 = a0, p1 = a1;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) bq[s] = bn[s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fold(7, r);
+    // register r = sub-pixel (dy, dx) = (r >> 1, r & 1) of shuffle channel co0 / 4 + g
+    const uint32_t o0 = (uint32_t)(k * Wd::FPC * D::YFRAME + obase);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[r][q] = fmaxf(y[r][q] + bv[r], 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {               // image row 4 ty + 2a + dy: columns (b, dx) = (0,0) (0,1) (1,0) (1,1)
+        const float4 row = make_float4(y[2 * dy][2 * a], y[2 * dy + 1][2 * a], y[2 * dy][2 * a + 1], y[2 * dy + 1][2 * a + 1]);
+        em_st4(ry, (o0 + (uint32_t)((2 * a + dy) * 2 * S)) * 4u, row);
+      }
+  };
+
+#define WN_COMPUTE(vr, k) do { if constexpr (PM) compute_p((vr), (k)); else compute_k((vr), (k)); } while (0)
+
   // pipeline: at step n, xin[(n+1)&1] holds set n+1, vt[n&1] the transformed set n, pre the frames of set n+2
   int64_t k = blockIdx.x;
   fetch(k);
@@ -259,7 +327,7 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
       transform(xin + K::CSX, vt + K::VSET);         // set n+1
     }
     WN_STAMP(slot, 1);
-    compute(vt, k);                                  // set n
+    WN_COMPUTE(vt, k);                               // set n
     WN_STAMP(slot, 2);
     if (!early) {
       stage(xin);
@@ -274,7 +342,7 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
       transform(xin, vt);
     }
     WN_STAMP(slot, 4);
-    compute(vt + K::VSET, k + stride);
+    WN_COMPUTE(vt + K::VSET, k + stride);
     WN_STAMP(slot, 5);
     if (!early) {
       stage(xin + K::CSX);

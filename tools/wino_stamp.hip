@@ -10,9 +10,9 @@ int main() {
   hipMalloc(&in, N * 2048 * 4); hipMalloc(&W, 36864 * 4); hipMalloc(&b, 512); hipMalloc(&out, N * 8192 * 4);
   hipMemset(in, 0, N * 2048 * 4); hipMemset(W, 0, 36864 * 4); hipMemset(b, 0, 512);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; ++rep) kvae::k_dec_up_fwd_wino<8><<<256, 512>>>(in, W, b, out, N);
+  for (int rep = 0; rep < 3; ++rep) kvae::k_dec_up_fwd_wino<8, true><<<256, 512>>>(in, W, b, out, N);
   hipEventRecord(e0);
-  kvae::k_dec_up_fwd_wino<8><<<256, 512>>>(in, W, b, out, N);
+  kvae::k_dec_up_fwd_wino<8, true><<<256, 512>>>(in, W, b, out, N);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -20,11 +20,12 @@ int main() {
   std::vector<unsigned long long> h(4096);
   hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(kvae::em_stamps), 4096 * 8);
   for (int w = 0; w < 2; ++w) {
-    printf("wave %d  slot: stage+xform | compute(mfma, epilogue) | barrier || stage+xform | compute | barrier || two sets (ticks of 10 ns)\n", 4 * w);
-    for (int s = 2; s < 14; ++s) {
+    printf("wave %d  slot: first part | second part | barrier || first | second | barrier || two sets (shader cycles; waves 0-3: shared "
+           "vector work then MFMAs + folds, waves 4-7: the reverse)\n", 4 * w);
+    for (int s = 4; s < 10; ++s) {
       unsigned long long *t = &h[(w * 120 + s) * 8];
-      printf("%2d: %5llu | %5llu (%5llu %5llu) | %5llu || %5llu | %5llu | %5llu || %6llu\n", s, t[1] - t[0], t[2] - t[1], t[7] > t[4] ? 0ull : t[7] - t[1],
-             t[7] > t[4] ? 0ull : t[2] - t[7], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[6] - t[0]);
+      printf("%2d: %5llu | %5llu | %5llu || %5llu | %5llu | %5llu || %6llu\n", s, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4],
+             t[6] - t[5], t[6] - t[0]);
     }
   }
   return 0;
