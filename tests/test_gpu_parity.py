@@ -364,3 +364,20 @@ def test_explicit_ones_mask_equals_no_mask():
     for x, y in zip(outs[0][1], outs[1][1]):
         if x is not None:
             assert rel_err(y.cpu(), x.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("env", [{"KVAE_WINO": "0"}, {"KVAE_WINO_PM": "0"}, {"KVAE_ELBO4": "0"}, {"KVAE_Q4": "0"}])
+def test_ab_switches_select_working_kernels(env):
+    """The A/B switches read once per process (direct instead of Winograd decoder blocks, k-step-major Winograd forward, one
+    step per wavefront in the n = 16 ELBO, one wavefront per sequence at n = 4) must select kernels that still pass parity: a
+    fresh process per switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import parity_cases as p; "
+            "p.dec_up_vs_torch('cuda', 7, 8); p.dec_up_vs_torch('cuda', 13, 4); "
+            "p.vs_oracle_random('cuda', 3, 10, 16, 16, 2, 2, dense_q=True); p.vs_oracle_random('cuda', 19, 11, 4, 4, 2, 3)"
+            % (root, os.path.join(root, "kalman-vae_amd"), os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
