@@ -22,9 +22,9 @@
 namespace kvae {
 
 typedef float wn_f4 __attribute__((ext_vector_type(4)));
-#ifdef KVAE_EM_STAMPS   // tools/wino_stamp.hip only: s_memtime stamps of workgroup 0, waves 0 and 4 (the two waves of SIMD 0)
-#define WN_STAMP(slot, k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (slot) < 120) \
-    em_stamps[((threadIdx.x >> 8) * 120 + (slot)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef KVAE_EM_STAMPS   // tools/wino_stamp*.hip only: s_memtime stamps of workgroup 0, every wave (waves w and w + 4 share a SIMD)
+#define WN_STAMP(slot, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (slot) < 40) \
+    em_stamps[((threadIdx.x >> 6) * 40 + (slot)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WN_STAMP(slot, k) do {} while (0)
 #endif
@@ -651,7 +651,9 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      dma_piece(knext, ks);                           // raw buffers are free since the convert phase
+      // the raw buffers are free since the convert phase; all pieces go out in the FIRST half of the set: the barrier that ends it
+      // drains the DMA, and a piece issued behind the last k-step showed up as ~1400 cycles of every wave waiting there (stamps)
+      if (ks < 2) dma_piece(knext, 2 * ks), dma_piece(knext, 2 * ks + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -663,14 +665,20 @@ __global__ __launch_bounds__(512) void k_dec_up_wrw_wino(const float *__restrict
   stage();
   fetch(k + stride);
   __syncthreads();
-  for (; k < nsets; k += stride) {
+  for (int slot = 0; k < nsets; k += stride, ++slot) {
+    WN_STAMP(slot, 0);
     convert();                                        // raw(k) -> gy4
+    WN_STAMP(slot, 1);
     transform();                                      // planes(k) -> vt
+    WN_STAMP(slot, 2);
     __syncthreads();
+    WN_STAMP(slot, 3);
     stage();                                          // planes <- x(k + stride)
     fetch(k + 2 * stride);
     compute(k + stride);                              // ... and the DMA of raw(k + stride), dealt out between the k-steps
+    WN_STAMP(slot, 4);
     __syncthreads();
+    WN_STAMP(slot, 5);
   }
   // G^T Z G per (co, ci), partial sums of this workgroup
   float *wp = w_partials + (int64_t)blockIdx.x * UP_W;

@@ -19,11 +19,11 @@ int main() {
   printf("kernel %.1f us (zero operands)\n", ms * 1e3);
   std::vector<unsigned long long> h(4096);
   hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(kvae::em_stamps), 4096 * 8);
-  for (int w = 0; w < 2; ++w) {
+  for (int w = 0; w < 8; ++w) {
     printf("wave %d  slot: first part | second part | barrier || first | second | barrier || two sets (shader cycles; waves 0-3: shared "
-           "vector work then MFMAs + folds, waves 4-7: the reverse)\n", 4 * w);
-    for (int s = 4; s < 10; ++s) {
-      unsigned long long *t = &h[(w * 120 + s) * 8];
+           "vector work then MFMAs + folds, waves 4-7: the reverse)\n", w);
+    for (int s = 6; s < 8; ++s) {
+      unsigned long long *t = &h[(w * 40 + s) * 8];
       printf("%2d: %5llu | %5llu | %5llu || %5llu | %5llu | %5llu || %6llu\n", s, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4],
              t[6] - t[5], t[6] - t[0]);
     }
