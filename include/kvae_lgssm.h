@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 6
+#define KVAE_ABI_VERSION 7
 
 typedef enum {
   KVAE_OK = 0,
@@ -260,9 +260,11 @@ int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, fl
 int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,
                       int32_t side, void *stream);
 /* Weight / bias gradient partials ([rows, Cout*9], [rows, Cout]) of the stem with the ReLU mask (out > 0) fused;
- * the input frames need no gradient. */
-int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, float *w_partials, float *b_partials,
-                      int64_t N, int32_t Cout, int32_t side, void *stream);
+ * the input frames need no gradient.  With W and bias given (may be NULL) the mask is recomputed from x - the same nine FMAs
+ * per output in the same order as kvae_enc_stem_fwd, hence the same sign bit for bit - and `out` (eight times the bytes of x)
+ * is not read at all. */
+int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, const float *W, const float *bias,
+                      float *w_partials, float *b_partials, int64_t N, int32_t Cout, int32_t side, void *stream);
 int64_t kvae_conv_edge_partial_rows(int64_t N);
 
 /* Encoder middle layers (kvae/vae/vae.py:20-31): out[N,32,s/2,s/2] = relu(conv3x3_stride2_pad1(in[N,32,s,s], W[32,32,3,3]) + b)

@@ -328,4 +328,107 @@ __global__ __launch_bounds__(256) void k_enc_stem_wrw(const float *__restrict__ 
   }
 }
 
+// The same weight gradient on the f32 matrix cores: per frame dW[32 co][9 taps] = Gm[32 x 256 pixels] Xp[256 pixels x 9 taps] is
+// 128 v_mfma_f32_16x16x4_f32 (two 16-channel halves x 64 k-steps of four pixels; the 16 tap columns carry the 9 taps, a column
+// of ones - which makes the bias gradient fall out of the same product - and six ignored ones).  The VALU version above spends
+// ten LDS reads and nine FMAs per (channel, pixel) and runs at 2.9 TB/s; here every MFMA costs one LDS read per operand and the
+// kernel is left with its 0.47 GB of g_out / out / x traffic.  Wave wv takes pixels 64 wv .. 64 wv + 63 of every frame.
+typedef float es_f4 __attribute__((ext_vector_type(4)));
+// REMASK: the ReLU mask is recomputed from the frame (thread = output pixel, the forward's own FMA chain per channel, one 32-bit
+// word of sign bits per pixel through LDS) instead of being read from `out`: 0.42 of the kernel's 0.89 GB at 12800 frames, and
+// the kernel is HBM-bound (6.1 TB/s with the mask read).
+template <bool REMASK>
+__global__ __launch_bounds__(256) void k_enc_stem_wrw_mfma(const float *__restrict__ x, const float *__restrict__ out,
+                                                           const float *__restrict__ g_out, const float *__restrict__ W,
+                                                           const float *__restrict__ bias, float *__restrict__ partial,
+                                                           float *__restrict__ partial_b, int64_t N) {
+  __shared__ float tile[34 * ES_TS];
+  // channel planes 260 floats apart: the masked gradient goes in as one ds_write_b128 per 16 bytes loaded.  With the 257 of the
+  // VALU version a wave's 64 scalar writes hit 8 banks - 32 eight-way-conflicting writes per thread and frame were the whole
+  // kernel: 158 us whether the products ran on the VALU or the matrix cores, with or without `out`, with or without prefetch.
+  constexpr int GS = 260;
+  __shared__ __attribute__((aligned(16))) float gt[ES_CO * GS];
+  __shared__ __attribute__((aligned(16))) uint32_t mw[256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int tap = j < 9 ? j : 8;
+  const float *tb = tile + (8 * wv) * ES_TS + 2 * g + (tap / 3) * ES_TS + tap % 3;   // pixel (4 wv + (s >> 2), 4 (s & 3) + g), tap j
+  const float *ga = gt + j * GS + 64 * wv + g;                                     // channel j (+16), pixel 64 wv + 4 s + g
+  es_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  // g_out / out of the NEXT frame are requested before this frame's MFMAs (16 x 16 bytes per thread in flight): fetched in a
+  // loop that also writes LDS, hipcc waits for every pair of loads before the next pair is issued - eight memory round trips
+  // per frame, which is what bound the VALU version (158 us with either arithmetic)
+  float4 gv[8], ov[8];
+  auto fetch = [&](int64_t n) {
+    const bool ok = n < N;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g_out + (ok ? n : 0) * ES_CO * 256);
+    const float4 *o4 = reinterpret_cast<const float4 *>(out + (ok ? n : 0) * ES_CO * 256);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      gv[q] = g4[threadIdx.x + 256 * q];
+      if constexpr (!REMASK) ov[q] = o4[threadIdx.x + 256 * q];
+    }
+  };
+  fetch(blockIdx.x);
+  for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+    __syncthreads();
+    es_load_tile(tile, x + n * 1024);
+    if constexpr (REMASK) {
+      __syncthreads();
+      const int oh = threadIdx.x >> 4, ow = threadIdx.x & 15;
+      float v[9];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = tile[(2 * oh + ky) * ES_TS + 2 * ow + kx];
+      uint32_t bits = 0;
+#pragma unroll 8
+      for (int co = 0; co < ES_CO; ++co) {
+        float acc = bias[co];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(W[co * 9 + k], v[k], acc);
+        bits |= (fmaxf(acc, 0.f) > 0.f ? 1u : 0u) << co;
+      }
+      mw[threadIdx.x] = bits;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = (threadIdx.x + 256 * q) * 4, c = e >> 8, hw = e & 255;
+      float4 md;
+      if constexpr (REMASK) {
+        const uint4 m = *reinterpret_cast<const uint4 *>(mw + hw);
+        md = make_float4((m.x >> c) & 1u ? gv[q].x : 0.f, (m.y >> c) & 1u ? gv[q].y : 0.f, (m.z >> c) & 1u ? gv[q].z : 0.f,
+                         (m.w >> c) & 1u ? gv[q].w : 0.f);
+      } else {
+        md = make_float4(ov[q].x > 0.f ? gv[q].x : 0.f, ov[q].y > 0.f ? gv[q].y : 0.f, ov[q].z > 0.f ? gv[q].z : 0.f,
+                         ov[q].w > 0.f ? gv[q].w : 0.f);
+      }
+      *reinterpret_cast<float4 *>(gt + c * GS + hw) = md;
+    }
+    __syncthreads();
+    fetch(n + gridDim.x);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float xb = tb[2 * (s >> 2) * ES_TS + 8 * (s & 3)];
+      const float b = j == 9 ? 1.0f : xb;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[4 * s], b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[16 * GS + 4 * s], b, acc1, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float *red = gt;   // [wave][channel 32][column 16]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    red[(wv * 32 + 4 * g + r) * 16 + j] = acc0[r];
+    red[(wv * 32 + 16 + 4 * g + r) * 16 + j] = acc1[r];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < ES_CO * 10; o += 256) {
+    const int c = o / 10, k = o - c * 10;
+    const float s = (red[c * 16 + k] + red[(32 + c) * 16 + k]) + (red[(64 + c) * 16 + k] + red[(96 + c) * 16 + k]);
+    if (k < 9) partial[(int64_t)blockIdx.x * (ES_CO * 9) + c * 9 + k] = s;
+    else partial_b[(int64_t)blockIdx.x * ES_CO + c] = s;
+  }
+}
+
 }  // namespace kvae

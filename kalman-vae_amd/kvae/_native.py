@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -111,7 +111,7 @@ class LgssmLib:
         d.kvae_dec_head_bwd.restype = C.c_int
         d.kvae_enc_stem_fwd.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_stem_fwd.restype = C.c_int
-        d.kvae_enc_stem_bwd.argtypes = [vp] * 5 + [C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_enc_stem_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_stem_bwd.restype = C.c_int
         d.kvae_enc_mid_fwd.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_mid_fwd.restype = C.c_int

@@ -121,21 +121,21 @@ class EncoderStem(torch.autograd.Function):
         lib = N.lib_for(x)
         lib.check(lib.dll.kvae_enc_stem_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cout, s, N.stream_for(x)),
                   "kvae_enc_stem_fwd")
-        ctx.save_for_backward(x, out)
+        ctx.save_for_backward(x, out, weight, bias)
         ctx.wshape = weight.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, out = ctx.saved_tensors
+        x, out, weight, bias = ctx.saved_tensors
         g = g.contiguous()
         Nb, Cout = out.shape[:2]
         lib = N.lib_for(x)
         rows = lib.dll.kvae_conv_edge_partial_rows(Nb)
         wp = torch.empty(rows, Cout * 9, device=x.device, dtype=torch.float32)
         bp = torch.empty(rows, Cout, device=x.device, dtype=torch.float32)
-        lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(g), N.ptr(wp), N.ptr(bp), Nb, Cout, x.shape[2],
-                                            N.stream_for(x)), "kvae_enc_stem_bwd")
+        lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(g), N.ptr(weight), N.ptr(bias), N.ptr(wp), N.ptr(bp), Nb, Cout,
+                                            x.shape[2], N.stream_for(x)), "kvae_enc_stem_bwd")
         gw, gb = colsum_pair(wp, bp)
         return None, gw.view(ctx.wshape), gb
 

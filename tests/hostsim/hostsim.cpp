@@ -404,8 +404,8 @@ int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *
         }
   return KVAE_OK;
 }
-int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, float *w_partials, float *b_partials,
-                      int64_t N, int32_t Cout, int32_t side, void *) {
+int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, const float *, const float *, float *w_partials,
+                      float *b_partials, int64_t N, int32_t Cout, int32_t side, void *) {   // (mask always from out here)
   if (!x || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cout != 32 || side != 32) return KVAE_ERR_DIMS;

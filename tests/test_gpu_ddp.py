@@ -113,4 +113,6 @@ def test_split_graph_with_a_real_rccl_communicator():
     assert p.exitcode == 0
     assert split2 and not split1
     assert np.isfinite(l2) and abs(l2 - l1) <= 1e-4 * abs(l1)
-    assert float(np.abs(p2 - p1).max()) < 2e-4
+    # the multi-rank path scales the flat gradient by the frame count and divides it out again after the all-reduce: last-bit
+    # differences, which four Adam steps of lr 7e-3 can turn into a few 1e-4 on parameters whose gradient is nearly zero
+    assert float(np.abs(p2 - p1).max()) < 2e-3
