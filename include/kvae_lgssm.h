@@ -256,15 +256,14 @@ int kvae_dec_head_fwd(const float *in, const float *W, const float *bias, float 
 int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, float *g_in, float *w_partials,
                       float *b_partials, float *w_scratch, int64_t N, int32_t Cin, int32_t side, void *stream);
 /* Encoder stem (kvae/vae/vae.py:20-31): out[N,Cout,s/2,s/2] = relu(conv3x3_stride2_pad1(x[N,1,s,s], W[Cout,1,3,3]) + b).
- * Built for Cout = 32, s = 32. */
-int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,
+ * Built for Cout = 32, s = 32.  relu_bits (may be NULL): [N, (s/2)^2] words, bit co of word (n, pixel) = out[n,co,pixel] > 0 -
+ * the ReLU mask in 1/32 of the bytes of out, for kvae_enc_stem_bwd. */
+int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, uint32_t *relu_bits, int64_t N, int32_t Cout,
                       int32_t side, void *stream);
-/* Weight / bias gradient partials ([rows, Cout*9], [rows, Cout]) of the stem with the ReLU mask (out > 0) fused;
- * the input frames need no gradient.  With W and bias given (may be NULL) the mask is recomputed from x - the same nine FMAs
- * per output in the same order as kvae_enc_stem_fwd, hence the same sign bit for bit - and `out` (eight times the bytes of x)
- * is not read at all. */
-int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, const float *W, const float *bias,
-                      float *w_partials, float *b_partials, int64_t N, int32_t Cout, int32_t side, void *stream);
+/* Weight / bias gradient partials ([rows, Cout*9], [rows, Cout]) of the stem with the ReLU mask fused; the input frames need
+ * no gradient.  The mask comes from relu_bits when given (then `out` is not read and may be NULL), else from out > 0. */
+int kvae_enc_stem_bwd(const float *x, const float *out, const uint32_t *relu_bits, const float *g_out, float *w_partials,
+                      float *b_partials, int64_t N, int32_t Cout, int32_t side, void *stream);
 int64_t kvae_conv_edge_partial_rows(int64_t N);
 
 /* Encoder middle layers (kvae/vae/vae.py:20-31): out[N,32,s/2,s/2] = relu(conv3x3_stride2_pad1(in[N,32,s,s], W[32,32,3,3]) + b)

@@ -902,25 +902,24 @@ int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, fl
                                                                                                      b_partials, N);
   return launch_status("k_dec_head_wrw");
 }
-int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,
+int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, uint32_t *relu_bits, int64_t N, int32_t Cout,
                       int32_t side, void *stream) {
   if (!x || !W || !bias || !out) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cout != ES_CO || side != ES_IN) return KVAE_ERR_DIMS;
-  k_enc_stem_fwd<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out);
+  k_enc_stem_fwd<<<dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, relu_bits);
   return launch_status("k_enc_stem_fwd");
 }
-int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, const float *W, const float *bias, float *w_partials,
+int kvae_enc_stem_bwd(const float *x, const float *out, const uint32_t *relu_bits, const float *g_out, float *w_partials,
                       float *b_partials, int64_t N, int32_t Cout, int32_t side, void *stream) {
-  const bool remask = W && bias;
-  if (!x || (!out && !remask) || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
+  if (!x || (!out && !relu_bits) || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
   if (Cout != ES_CO || side != ES_IN) return KVAE_ERR_DIMS;
-  static const int mfma = getenv("KVAE_STEM_MFMA") ? atoi(getenv("KVAE_STEM_MFMA")) : 1;   // 0: VALU version (A/B runs), 2: mask read from out
+  static const int mfma = getenv("KVAE_STEM_MFMA") ? atoi(getenv("KVAE_STEM_MFMA")) : 1;   // 0: VALU version, 2: mask from out (A/B runs)
   const dim3 grid((unsigned)kvae_conv_edge_partial_rows(N));
-  if (mfma == 1 && remask) k_enc_stem_wrw_mfma<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, W, bias, w_partials, b_partials, N);
+  if (mfma == 1 && relu_bits) k_enc_stem_wrw_mfma<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, relu_bits, g_out, w_partials, b_partials, N);
   else if (!out) return KVAE_ERR_NULL;
-  else if (mfma) k_enc_stem_wrw_mfma<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, W, bias, w_partials, b_partials, N);
+  else if (mfma) k_enc_stem_wrw_mfma<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, relu_bits, g_out, w_partials, b_partials, N);
   else k_enc_stem_wrw<<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, out, g_out, w_partials, b_partials, N);
   return launch_status("k_enc_stem_wrw");
 }

@@ -257,7 +257,8 @@ __device__ __forceinline__ void es_load_tile(float *tile, const float *__restric
 }
 
 __global__ __launch_bounds__(256) void k_enc_stem_fwd(const float *__restrict__ x, const float *__restrict__ W,
-                                                      const float *__restrict__ bias, float *__restrict__ out) {
+                                                      const float *__restrict__ bias, float *__restrict__ out,
+                                                      uint32_t *__restrict__ relu_bits) {
   __shared__ float tile[34 * ES_TS];
   const int64_t n = blockIdx.x;
   es_load_tile(tile, x + n * 1024);
@@ -269,13 +270,16 @@ __global__ __launch_bounds__(256) void k_enc_stem_fwd(const float *__restrict__ 
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = tile[(2 * oh + ky) * ES_TS + 2 * ow + kx];
   float *o = out + n * ES_CO * 256 + threadIdx.x;
+  uint32_t bits = 0;                                  // the thread walks all 32 channels of its pixel: their ReLU mask is one word
 #pragma unroll 8
   for (int co = 0; co < ES_CO; ++co) {
     float acc = bias[co];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc = fmaf(W[co * 9 + k], v[k], acc);
     o[co * 256] = fmaxf(acc, 0.f);
+    bits |= (acc > 0.f ? 1u : 0u) << co;
   }
+  if (relu_bits) relu_bits[n * 256 + threadIdx.x] = bits;
 }
 
 // partial[blk, co, k] = sum_frames sum_{oh,ow} gm[n,co,oh,ow] x[n, 2oh+ky-1, 2ow+kx-1], gm = g_out * (out > 0);
@@ -334,13 +338,14 @@ __global__ __launch_bounds__(256) void k_enc_stem_wrw(const float *__restrict__ 
 // ten LDS reads and nine FMAs per (channel, pixel) and runs at 2.9 TB/s; here every MFMA costs one LDS read per operand and the
 // kernel is left with its 0.47 GB of g_out / out / x traffic.  Wave wv takes pixels 64 wv .. 64 wv + 63 of every frame.
 typedef float es_f4 __attribute__((ext_vector_type(4)));
-// REMASK: the ReLU mask is recomputed from the frame (thread = output pixel, the forward's own FMA chain per channel, one 32-bit
-// word of sign bits per pixel through LDS) instead of being read from `out`: 0.42 of the kernel's 0.89 GB at 12800 frames, and
-// the kernel is HBM-bound (6.1 TB/s with the mask read).
-template <bool REMASK>
+// BITS: the ReLU mask comes as one 32-bit word per pixel (written by the forward: 1 KB per frame instead of the 32 KB of `out`,
+// 0.42 of this kernel's 0.89 GB).  What the parts cost at 12800 frames (tools/stem_wrw_diag.hip, compiled out one at a time):
+// streaming g_out alone 70 us (6.7 TB/s), + LDS staging 9, + frame tile 29 (loaded synchronously: now prefetched), + MFMAs 37,
+// and recomputing the mask from the frame with the forward's FMA chain 56 - as much as reading `out`; hence the words.
+template <bool BITS>
 __global__ __launch_bounds__(256) void k_enc_stem_wrw_mfma(const float *__restrict__ x, const float *__restrict__ out,
-                                                           const float *__restrict__ g_out, const float *__restrict__ W,
-                                                           const float *__restrict__ bias, float *__restrict__ partial,
+                                                           const uint32_t *__restrict__ relu_bits, const float *__restrict__ g_out,
+                                                           float *__restrict__ partial,
                                                            float *__restrict__ partial_b, int64_t N) {
   __shared__ float tile[34 * ES_TS];
   // channel planes 260 floats apart: the masked gradient goes in as one ds_write_b128 per 16 bytes loaded.  With the 257 of the
@@ -357,7 +362,8 @@ __global__ __launch_bounds__(256) void k_enc_stem_wrw_mfma(const float *__restri
   // g_out / out of the NEXT frame are requested before this frame's MFMAs (16 x 16 bytes per thread in flight): fetched in a
   // loop that also writes LDS, hipcc waits for every pair of loads before the next pair is issued - eight memory round trips
   // per frame, which is what bound the VALU version (158 us with either arithmetic)
-  float4 gv[8], ov[8];
+  float4 gv[8], ov[8], xv;
+  uint32_t mv = 0;
   auto fetch = [&](int64_t n) {
     const bool ok = n < N;
     const float4 *g4 = reinterpret_cast<const float4 *>(g_out + (ok ? n : 0) * ES_CO * 256);
@@ -365,37 +371,28 @@ __global__ __launch_bounds__(256) void k_enc_stem_wrw_mfma(const float *__restri
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       gv[q] = g4[threadIdx.x + 256 * q];
-      if constexpr (!REMASK) ov[q] = o4[threadIdx.x + 256 * q];
+      if constexpr (!BITS) ov[q] = o4[threadIdx.x + 256 * q];
     }
+    xv = reinterpret_cast<const float4 *>(x + (ok ? n : 0) * 1024)[threadIdx.x];
+    if constexpr (BITS) mv = relu_bits[(ok ? n : 0) * 256 + threadIdx.x];
   };
   fetch(blockIdx.x);
+  for (int i = threadIdx.x; i < 34 * ES_TS; i += 256) tile[i] = 0.f;   // the border stays zero for the whole kernel
   for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
     __syncthreads();
-    es_load_tile(tile, x + n * 1024);
-    if constexpr (REMASK) {
-      __syncthreads();
-      const int oh = threadIdx.x >> 4, ow = threadIdx.x & 15;
-      float v[9];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = tile[(2 * oh + ky) * ES_TS + 2 * ow + kx];
-      uint32_t bits = 0;
-#pragma unroll 8
-      for (int co = 0; co < ES_CO; ++co) {
-        float acc = bias[co];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc = fmaf(W[co * 9 + k], v[k], acc);
-        bits |= (fmaxf(acc, 0.f) > 0.f ? 1u : 0u) << co;
-      }
-      mw[threadIdx.x] = bits;
+    {                                                 // frame row h = tid / 8, columns 4 (tid & 7) ..: interior of the zero-bordered tile
+      float *d = tile + ((threadIdx.x >> 3) + 1) * ES_TS + 4 * (threadIdx.x & 7) + 1;
+      d[0] = xv.x; d[1] = xv.y; d[2] = xv.z; d[3] = xv.w;
+    }
+    if constexpr (BITS) {
+      mw[threadIdx.x] = mv;
       __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int e = (threadIdx.x + 256 * q) * 4, c = e >> 8, hw = e & 255;
       float4 md;
-      if constexpr (REMASK) {
+      if constexpr (BITS) {
         const uint4 m = *reinterpret_cast<const uint4 *>(mw + hw);
         md = make_float4((m.x >> c) & 1u ? gv[q].x : 0.f, (m.y >> c) & 1u ? gv[q].y : 0.f, (m.z >> c) & 1u ? gv[q].z : 0.f,
                          (m.w >> c) & 1u ? gv[q].w : 0.f);

@@ -109,9 +109,9 @@ class LgssmLib:
         d.kvae_dec_head_fwd.restype = C.c_int
         d.kvae_dec_head_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_dec_head_bwd.restype = C.c_int
-        d.kvae_enc_stem_fwd.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_enc_stem_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_stem_fwd.restype = C.c_int
-        d.kvae_enc_stem_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, C.c_int32, vp]
+        d.kvae_enc_stem_bwd.argtypes = [vp] * 6 + [C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_stem_bwd.restype = C.c_int
         d.kvae_enc_mid_fwd.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
         d.kvae_enc_mid_fwd.restype = C.c_int

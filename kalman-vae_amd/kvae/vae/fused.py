@@ -119,23 +119,25 @@ class EncoderStem(torch.autograd.Function):
         Cout = weight.shape[0]
         out = torch.empty(Nb, Cout, s // 2, s // 2, device=x.device, dtype=torch.float32)
         lib = N.lib_for(x)
-        lib.check(lib.dll.kvae_enc_stem_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), Nb, Cout, s, N.stream_for(x)),
-                  "kvae_enc_stem_fwd")
-        ctx.save_for_backward(x, out, weight, bias)
+        # one word of ReLU sign bits per output pixel (32 channels): the weight gradient reads these instead of `out`
+        bits = torch.empty(Nb, (s // 2) ** 2, device=x.device, dtype=torch.int32) if (x.is_cuda and Cout == 32) else None
+        lib.check(lib.dll.kvae_enc_stem_fwd(N.ptr(x), N.ptr(weight), N.ptr(bias), N.ptr(out), N.ptr(bits) if bits is not None else None,
+                                            Nb, Cout, s, N.stream_for(x)), "kvae_enc_stem_fwd")
+        ctx.save_for_backward(x, out, bits)
         ctx.wshape = weight.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, out, weight, bias = ctx.saved_tensors
+        x, out, bits = ctx.saved_tensors
         g = g.contiguous()
         Nb, Cout = out.shape[:2]
         lib = N.lib_for(x)
         rows = lib.dll.kvae_conv_edge_partial_rows(Nb)
         wp = torch.empty(rows, Cout * 9, device=x.device, dtype=torch.float32)
         bp = torch.empty(rows, Cout, device=x.device, dtype=torch.float32)
-        lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(g), N.ptr(weight), N.ptr(bias), N.ptr(wp), N.ptr(bp), Nb, Cout,
-                                            x.shape[2], N.stream_for(x)), "kvae_enc_stem_bwd")
+        lib.check(lib.dll.kvae_enc_stem_bwd(N.ptr(x), N.ptr(out), N.ptr(bits) if bits is not None else None, N.ptr(g), N.ptr(wp),
+                                            N.ptr(bp), Nb, Cout, x.shape[2], N.stream_for(x)), "kvae_enc_stem_bwd")
         gw, gb = colsum_pair(wp, bp)
         return None, gw.view(ctx.wshape), gb
 

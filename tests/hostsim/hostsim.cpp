@@ -383,7 +383,7 @@ int kvae_dec_head_bwd(const float *in, const float *W, const float *g_logits, fl
   }
   return KVAE_OK;
 }
-int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cout,
+int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *out, uint32_t *, int64_t N, int32_t Cout,
                       int32_t side, void *) {
   if (!x || !W || !bias || !out) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
@@ -404,7 +404,7 @@ int kvae_enc_stem_fwd(const float *x, const float *W, const float *bias, float *
         }
   return KVAE_OK;
 }
-int kvae_enc_stem_bwd(const float *x, const float *out, const float *g_out, const float *, const float *, float *w_partials,
+int kvae_enc_stem_bwd(const float *x, const float *out, const uint32_t *, const float *g_out, float *w_partials,
                       float *b_partials, int64_t N, int32_t Cout, int32_t side, void *) {   // (mask always from out here)
   if (!x || !out || !g_out || !w_partials || !b_partials) return KVAE_ERR_NULL;
   if (N < 1) return KVAE_ERR_ARG;
