@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   __shared__ float redb[8 * DH_CO];
   float *tile = lds, *gt = lds + DH_CI * CS;
   const int ci = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  // which 16 bytes of the frame a thread stages: sixteen lanes per channel plane, four planes per wave - consecutive lanes
+  // inside one 256-float plane make the four scalar writes per 16 bytes (planes are padded by one float) 8-way bank conflicts
+  const int tin = (((threadIdx.x & 63) >> 4) << 6) | ((threadIdx.x >> 6) << 4) | (threadIdx.x & 15);
   kv_f2 acc[DH_CO / 2][9];
   float accb[DH_CO];
 #pragma unroll
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   if (n < N) {
     const float4 *src = reinterpret_cast<const float4 *>(in + n * DH_CI * 256);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pre[j] = src[threadIdx.x + 256 * j];
+    for (int j = 0; j < 8; ++j) pre[j] = src[tin + 256 * j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) gp[j] = g_logits[n * 1024 + threadIdx.x + 256 * j];
   }
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
     __syncthreads();                                  // previous frame's tile fully consumed
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int e = (threadIdx.x + 256 * j) * 4;
+      const int e = (tin + 256 * j) * 4;
       float *d = tile + (e >> 8) * CS + (e & 255);
       d[0] = pre[j].x; d[1] = pre[j].y; d[2] = pre[j].z; d[3] = pre[j].w;
     }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
     if (nn < N) {
       const float4 *src = reinterpret_cast<const float4 *>(in + nn * DH_CI * 256);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pre[j] = src[threadIdx.x + 256 * j];
+      for (int j = 0; j < 8; ++j) pre[j] = src[tin + 256 * j];
 #pragma unroll
       for (int j = 0; j < 4; ++j) gp[j] = g_logits[nn * 1024 + threadIdx.x + 256 * j];
     }

@@ -300,9 +300,14 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
                                ro = em_rsrc(out, total_out * 4);
   float4 px[16], pg[4], po[4];
   int64_t it = blockIdx.x;
+  // Which 16 bytes of an input piece a thread moves.  With 256-float channel planes (S = 16) consecutive lanes would stay inside
+  // ONE plane, and the four scalar LDS writes per 16 bytes (planes are padded by one float for the B-operand reads) then hit 8
+  // banks with 64 lanes: an 8-way conflict on 64 writes per thread and iteration.  Sixteen lanes per plane, four planes per wave
+  // instead: 32 banks, two lanes each; the loads stay 256-byte contiguous per 16 lanes.
+  const int tin = S == 16 ? ((lane >> 4) << 6) | (wv << 4) | (lane & 15) : tid;
   auto fetch1 = [&](int64_t i, int j) {                 // 24 pieces: 16 of in, 4 of g_out, 4 of out
     if (j < 16) {
-      px[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tid + 256 * ((j + rot) & 15)) * 4) * 4u);
+      px[j] = em_ld4(rin, (uint32_t)(i * D::IT_IN + (tin + 256 * ((j + rot) & 15)) * 4) * 4u);
     } else {
       const uint32_t e = (uint32_t)(i * D::IT_OUT + (tid + 256 * (((j & 3) + rot) & 3)) * 4) * 4u;
       if (j < 20) pg[j - 16] = em_ld4(rg, e);
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void k_enc_mid_wrw(const float *__restrict__ i
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int e = (tid + 256 * ((j + rot) & 15)) * 4, f = e / D::FRAME, c = (e % D::FRAME) / D::PLANE, p = e % D::PLANE;
+      const int e = (tin + 256 * ((j + rot) & 15)) * 4, f = e / D::FRAME, c = (e % D::FRAME) / D::PLANE, p = e % D::PLANE;
       float *d = xin + (f * EM_C + c) * CSP + p;
       d[0] = px[j].x; d[1] = px[j].y; d[2] = px[j].z; d[3] = px[j].w;
     }
