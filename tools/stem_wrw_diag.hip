@@ -1,5 +1,6 @@
-// Diagnostic: k_enc_stem_wrw_mfma<true> at 12800 frames with parts compiled out (-DES_DIAG=bits: 1 mask arithmetic, 2 MFMAs,
-// 4 frame tile load, 8 LDS staging writes).  hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DES_DIAG=n] -Ikalman-vae_amd/csrc tools/stem_wrw_diag.hip
+// k_enc_stem_wrw_mfma<true> alone at 12800 frames (HIP events).  The per-part costs quoted in DESIGN.md section 4b came from this
+// harness with parts of the kernel compiled out one at a time (mask arithmetic, MFMAs, frame tile load, LDS staging writes:
+// temporary #if blocks, not kept in the kernel).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ikalman-vae_amd/csrc -Iinclude tools/stem_wrw_diag.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "vae_conv_edge.h"
@@ -15,9 +16,6 @@ int main() {
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
-#ifndef ES_DIAG
-#define ES_DIAG 0
-#endif
-  printf("ES_DIAG=%d: %.1f us per launch (%.2f TB/s of 0.47 GB)\n", ES_DIAG, ms * 200, 0.471e9 / (ms * 200e-6) / 1e12);
+  printf("%.1f us per launch (%.2f TB/s of 0.47 GB)\n", ms * 200, 0.471e9 / (ms * 200e-6) / 1e12);
   return 0;
 }
