@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256) void k_dec_head_wrw(const float *__restrict__ 
   }
 }
 
+// (An f32-MFMA version of this weight gradient - D[ci 32][(co, tap) 36 of 48] += A[ci][4 pixels] B[4 pixels][(co, tap)], the
+//  gradient read at the tap-shifted pixel from zero-bordered planes, 24 accumulator registers, four workgroups per CU - was
+//  written and measured in round 2: 143 us against 153 alone, no difference on the training step; not kept.)
+
 // ------------------------------------------------------------------------------------------------------------------
 // encoder stem: x [N,1,32,32] -> out [N,32,16,16] = relu(conv3x3_stride2_pad1(x, W[32,1,3,3]) + b[32])
 // ------------------------------------------------------------------------------------------------------------------
