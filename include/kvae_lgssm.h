@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 7
+#define KVAE_ABI_VERSION 8
 
 typedef enum {
   KVAE_OK = 0,
@@ -234,6 +234,20 @@ int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, v
  * pairs, and a launch of a few microseconds of work costs as much again in the stream). */
 int kvae_colsum2(const float *partials_a, float *out_a, int64_t rows_a, int64_t cols_a, const float *partials_b, float *out_b,
                  int64_t rows_b, int64_t cols_b, void *stream);
+
+/* ---- optimizer step on flat buffers (reference train.py:52-56: clip_grad_norm_ + Adam.step) ------------------- */
+
+/* One training step's tail on four flat fp32 buffers of n elements (parameters, gradients, Adam's exp_avg and exp_avg_sq):
+ *   g <- g / max(*div_dev, 1)  (div_dev may be NULL: the multi-rank frame count);  total = ||g||_2  -> *norm_out (may be NULL);
+ *   g <- g * min(1, clip / (total + 1e-6))  if clip > 0   (torch.nn.utils.clip_grad_norm_);
+ *   *step_dev += 1;  Adam exactly as torch's fused kernel computes it (L2 weight decay added to g, exp_avg lerp,
+ *   step_size = lr / (1 - beta1^step), denom = sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).
+ * lr is read from *lr_dev when given (a device scalar follows the LR schedule under hipGraph replay), else from `lr`.
+ * The gradient buffer is left unscaled (it is overwritten by the next step).  ws: >= 1024 floats.  Two launches, fixed
+ * summation order. */
+int kvae_clip_adam(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr_dev,
+                   float lr, float *step_dev, float beta1, float beta2, float eps, float weight_decay, float clip,
+                   const float *div_dev, float *norm_out, float *ws, void *stream);
 
 /* ---- fused Bernoulli reconstruction term of the frame VAE --------------------------------- */
 

@@ -733,6 +733,77 @@ int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHU
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam on flat buffers: two launches instead of ~12 (norm, clamp, reciprocal, scale, three foreach kernels)
+// ---------------------------------------------------------------------------------------------
+constexpr int CA_BLOCKS = 512;   // partial sums of squares (ws[0..CA_BLOCKS))
+__global__ __launch_bounds__(256) void k_grad_sumsq(const float *__restrict__ g, int64_t n, const float *__restrict__ div_dev,
+                                                    float *__restrict__ step_dev, float *__restrict__ ws) {
+  __shared__ float red[256];
+  const float inv = div_dev ? 1.0f / fmaxf(*div_dev, 1.0f) : 1.0f;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = g[i] * inv;
+    s = fmaf(v, v, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = red[0];
+    if (blockIdx.x == 0) *step_dev += 1.0f;          // the next launch reads the incremented step
+  }
+}
+__global__ __launch_bounds__(256) void k_clip_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, const float *__restrict__ lr_dev, float lr,
+                                                   const float *__restrict__ step_dev, float beta1, float beta2, float eps,
+                                                   float wd, float clip, const float *__restrict__ div_dev,
+                                                   float *__restrict__ norm_out, const float *__restrict__ ws, int nparts) {
+  __shared__ float red[256];
+  float s = 0.f;                                      // every block folds the same partials in the same order
+  for (int i = threadIdx.x; i < nparts; i += 256) s += ws[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float total = sqrtf(red[0]);
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
+  const float inv = div_dev ? 1.0f / fmaxf(*div_dev, 1.0f) : 1.0f;
+  const float scale = inv * (clip > 0.f ? fminf(clip / (total + 1e-6f), 1.0f) : 1.0f);
+  const float step = *step_dev, lrv = lr_dev ? *lr_dev : lr;
+  const float bc1 = 1.0f - powf(beta1, step), bc2s = sqrtf(1.0f - powf(beta2, step));
+  const float step_size = lrv / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * scale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);          // lerp
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi, v[i] = vi;
+    p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + eps);
+  }
+}
+extern "C" int kvae_clip_adam(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr_dev,
+                              float lr, float *step_dev, float beta1, float beta2, float eps, float weight_decay, float clip,
+                              const float *div_dev, float *norm_out, float *ws, void *stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_dev || !ws) return KVAE_ERR_NULL;
+  if (n < 1) return KVAE_ERR_ARG;
+  const int64_t want = (n + 1023) / 1024;
+  const unsigned parts = (unsigned)(want < CA_BLOCKS ? want : CA_BLOCKS);
+  k_grad_sumsq<<<dim3(parts), dim3(256), 0, (hipStream_t)stream>>>(grads, n, div_dev, step_dev, ws);
+  int rc = launch_status("k_grad_sumsq");
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  k_clip_adam<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, lr_dev, lr, step_dev, beta1,
+                                                                   beta2, eps, weight_decay, clip, div_dev, norm_out, ws, (int)parts);
+  return launch_status("k_clip_adam");
+}
+
+// ---------------------------------------------------------------------------------------------
 // regime chain of the switching dynamics (regime.h)
 // ---------------------------------------------------------------------------------------------
 #include "regime.h"

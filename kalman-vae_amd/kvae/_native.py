@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -47,7 +47,7 @@ class InputGrads(C.Structure):  # kvae_lgssm_input_grads
 
 SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_alpha_lstm_bwd", "kvae_lgssm_filter_fwd", "kvae_lgssm_rts_fwd", "kvae_lgssm_smooth_fwd", "kvae_lgssm_smooth_bwd",
            "kvae_lgssm_elbo", "kvae_mix_fwd", "kvae_mix_bwd", "kvae_mix_bwd_partials", "kvae_lstm_fwd",
-           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_colsum2", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
+           "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_colsum2", "kvae_clip_adam", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
            "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows",
@@ -149,6 +149,9 @@ class LgssmLib:
         d.kvae_colsum.restype = C.c_int
         d.kvae_colsum2.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp]
         d.kvae_colsum2.restype = C.c_int
+        d.kvae_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_float, vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, vp, vp, vp, vp]
+        d.kvae_clip_adam.restype = C.c_int
         d.kvae_bias_partial_rows.argtypes = [C.c_int64]
         d.kvae_bias_partial_rows.restype = C.c_int64
         d.kvae_abi_version.restype = C.c_int

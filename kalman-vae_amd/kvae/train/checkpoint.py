@@ -46,4 +46,7 @@ def load_checkpoint(path, model, optimizer=None, map_location="cpu"):
             if isinstance(t, torch.Tensor):
                 t.fill_(float(g["lr"]))
                 g["lr"] = t
+        relink = getattr(optimizer, "_kvae_relink", None)   # a Trainer's optimizer: its state lives in flat buffers
+        if relink is not None:
+            relink()
     return {k: v for k, v in payload.items() if k not in ("model_state", "optimizer_state")}

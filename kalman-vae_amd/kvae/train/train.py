@@ -54,6 +54,11 @@ class Trainer:
         # updates it with fill_() - the decay of train.py:268-269 then reaches a captured step (a float would be baked in)
         self.lr_t = torch.tensor(float(lr), device=dev, dtype=torch.float32) if on_gpu else float(lr)
         self.opt = torch.optim.Adam(self.params, lr=self.lr_t, weight_decay=weight_decay, capturable=on_gpu, fused=on_gpu)
+        self._flat_step = (on_gpu and all(p.dtype == torch.float32 for p in self.params)
+                           and os.environ.get("KVAE_FLAT_ADAM", "1") != "0")   # 0: torch's fused Adam + aten clip (A/B runs)
+        if self._flat_step:
+            self._flatten_optimizer(n_par, dev)
+            self.opt._kvae_relink = self.relink_optimizer_state
         dyn = model.kalman_filter.dyn_params
         if on_gpu and hasattr(dyn, "tau_scalar"):
             dyn.tau_scalar(dev)   # create the device scalar of tau outside any capture
@@ -107,9 +112,69 @@ class Trainer:
             dist.all_reduce(self._flat)   # sum of count-weighted gradients and, in the last slot, of the counts
 
     def _clip_and_update(self):
+        if self._flat_step:
+            self._clip_and_update_flat()      # (divides by the all-reduced frame count itself when world > 1)
+            return
         if self.world > 1:
             self.flat_grad.div_(self._count.clamp(min=1.0))
         self._clip_and_update_local()
+
+    # -- clip + Adam as two launches on flat buffers (GPU) --------------------------------------------------
+    def _flatten_optimizer(self, n_par, dev):
+        """Parameters, exp_avg and exp_avg_sq become views of three flat buffers, so that clip_grad_norm_ + Adam.step are
+        kvae_clip_adam's two launches instead of a dozen (norm, clamp, reciprocal, scale, the foreach kernels of the fused
+        Adam).  `self.opt` stays a torch.optim.Adam whose state ENTRIES are those views: state_dict() / LR schedulers /
+        the reference-format checkpoint see an ordinary Adam; only step() is never called on it."""
+        self._flat_p = torch.empty(n_par, device=dev, dtype=torch.float32)
+        self._flat_m = torch.zeros(n_par, device=dev, dtype=torch.float32)
+        self._flat_v = torch.zeros(n_par, device=dev, dtype=torch.float32)
+        self._step_t = torch.zeros((), device=dev, dtype=torch.float32)
+        self._norm_t = torch.zeros((), device=dev, dtype=torch.float32)
+        self._ca_ws = torch.empty(1024, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                view = self._flat_p[off:off + n].view_as(p)
+                view.copy_(p)
+                p.data = view
+                off += n
+        self._link_state()
+
+    def _link_state(self, take_values=False):
+        """(Re)point self.opt.state at the flat moment buffers; take_values: first copy what the state currently holds
+        (after Optimizer.load_state_dict, which replaces the tensors) into them."""
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                m, v = self._flat_m[off:off + n].view_as(p), self._flat_v[off:off + n].view_as(p)
+                st = self.opt.state.get(p)
+                if take_values and st:
+                    m.copy_(st["exp_avg"]), v.copy_(st["exp_avg_sq"])
+                    self._step_t.fill_(float(st["step"]))
+                self.opt.state[p] = {"step": self._step_t, "exp_avg": m, "exp_avg_sq": v}
+                off += n
+
+    def relink_optimizer_state(self):
+        """Call after self.opt.load_state_dict(...) (kvae.train.checkpoint.load_checkpoint does)."""
+        if self._flat_step:
+            self._link_state(take_values=True)
+
+    def _clip_and_update_flat(self):
+        from .. import _native
+        g = self.opt.param_groups[0]
+        lib = _native.lib_for(self._flat_p)
+        lr = g["lr"]
+        b1, b2 = g["betas"]
+        lib.check(lib.dll.kvae_clip_adam(
+            _native.ptr(self._flat_p), _native.ptr(self.flat_grad), _native.ptr(self._flat_m), _native.ptr(self._flat_v),
+            self._flat_p.numel(), _native.ptr(lr) if isinstance(lr, torch.Tensor) else None,
+            0.0 if isinstance(lr, torch.Tensor) else float(lr), _native.ptr(self._step_t), float(b1), float(b2), float(g["eps"]),
+            float(g["weight_decay"]), float(self.clip or 0.0), _native.ptr(self._count) if self.world > 1 else None,
+            _native.ptr(self._norm_t), _native.ptr(self._ca_ws), _native.stream_for(self._flat_p)), "kvae_clip_adam")
+        if self.clip and self.clip > 0:
+            self.out["grad_norm"] = self._norm_t
 
     def _clip_and_update_local(self):
         if self.clip and self.clip > 0:   # torch.nn.utils.clip_grad_norm_ on the flat view of all grads

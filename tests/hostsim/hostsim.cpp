@@ -227,6 +227,28 @@ int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, v
   }
   return KVAE_OK;
 }
+int kvae_clip_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *lr_dev, float lr, float *step_dev,
+                   float beta1, float beta2, float eps, float wd, float clip, const float *div_dev, float *norm_out, float *ws,
+                   void *) {
+  if (!p || !g || !m || !v || !step_dev || !ws) return KVAE_ERR_NULL;
+  if (n < 1) return KVAE_ERR_ARG;
+  const float inv = div_dev ? 1.0f / std::fmax(*div_dev, 1.0f) : 1.0f;
+  double ss = 0.0;
+  for (int64_t i = 0; i < n; ++i) ss += (double)(g[i] * inv) * (g[i] * inv);
+  const float total = (float)std::sqrt(ss);
+  if (norm_out) *norm_out = total;
+  *step_dev += 1.0f;
+  const float scale = inv * (clip > 0.f ? std::fmin(clip / (total + 1e-6f), 1.0f) : 1.0f), lrv = lr_dev ? *lr_dev : lr;
+  const float bc1 = 1.0f - std::pow(beta1, *step_dev), bc2s = std::sqrt(1.0f - std::pow(beta2, *step_dev)), step_size = lrv / bc1;
+  for (int64_t i = 0; i < n; ++i) {
+    float gi = g[i] * scale;
+    if (wd != 0.f) gi += wd * p[i];
+    m[i] = m[i] + (gi - m[i]) * (1.0f - beta1);
+    v[i] = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    p[i] -= step_size * m[i] / (std::sqrt(v[i]) / bc2s + eps);
+  }
+  return KVAE_OK;
+}
 int kvae_colsum2(const float *pa, float *oa, int64_t rows_a, int64_t cols_a, const float *pb, float *ob, int64_t rows_b,
                  int64_t cols_b, void *s) {
   const int rc = kvae_colsum(pa, oa, rows_a, cols_a, s);

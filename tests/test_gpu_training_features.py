@@ -189,3 +189,40 @@ def test_reference_shaped_loop_body(kind):
     with noise.inject(**nz):
         first = tr.step(x)
     assert abs(float(first["loss"]) - losses[0][0]) < 1e-4 * abs(losses[0][0])
+
+
+def test_flat_clip_adam_equals_torch_adam(monkeypatch):
+    """kvae_clip_adam (clip_grad_norm_ + Adam on flat buffers, two launches) against torch.linalg.vector_norm + torch's fused Adam
+    on the same gradients: three eager steps with a learning-rate change in between, weight decay on; parameters, moments and the
+    reported gradient norm must agree to rounding, and the optimizer's state_dict must read like an ordinary Adam's."""
+    from kvae import noise
+    from kvae.train.synthetic import bouncing_ball
+    from kvae.train.train import Trainer
+    B, T = 6, 9
+    x = bouncing_ball(B, T, 3).float().to(DEV)
+    nz = _noise(B, T, seed=11)
+
+    def run(flat):
+        monkeypatch.setenv("KVAE_FLAT_ADAM", "1" if flat else "0")
+        model = _model("lstm", seed=5)
+        tr = Trainer(model, lr=3e-3, weight_decay=1e-3, grad_clip_norm=0.5, use_graph=False)
+        assert tr._flat_step is flat
+        norms = []
+        with noise.inject(**nz):
+            for i in range(3):
+                out = tr.step(x)
+                norms.append(float(out["grad_norm"]))
+                if i == 0:
+                    tr.set_lr(1e-3)
+        sd = tr.opt.state_dict()
+        flatp = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+        m = torch.cat([sd["state"][i]["exp_avg"].flatten() for i in range(len(tr.params))]).cpu()
+        v = torch.cat([sd["state"][i]["exp_avg_sq"].flatten() for i in range(len(tr.params))]).cpu()
+        return flatp, m, v, norms, float(sd["state"][0]["step"])
+
+    pf, mf, vf, nf, sf = run(True)
+    pt, mt, vt, nt, st = run(False)
+    assert sf == st == 3.0
+    assert max(abs(a - b) / b for a, b in zip(nf, nt)) < 1e-5 and nt[0] > 0.5          # the clip was active
+    assert float((pf - pt).abs().max()) < 2e-6
+    assert rel_err(mf, mt) < 1e-5 and rel_err(vf, vt) < 5e-5   # (the second moment squares the clip scale: twice its rounding)
