@@ -175,6 +175,7 @@ class Trainer:
             _native.ptr(self._norm_t), _native.ptr(self._ca_ws), _native.stream_for(self._flat_p)), "kvae_clip_adam")
         if self.clip and self.clip > 0:
             self.out["grad_norm"] = self._norm_t
+        self.opt._opt_called = True   # what Optimizer.step's wrapper records; LRScheduler.step() checks it to warn about call order
 
     def _clip_and_update_local(self):
         if self.clip and self.clip > 0:   # torch.nn.utils.clip_grad_norm_ on the flat view of all grads
