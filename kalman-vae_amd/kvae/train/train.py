@@ -113,6 +113,7 @@ class Trainer:
 
     def _clip_and_update(self):
         if self._flat_step:
+            assert len(self.opt.param_groups) == 1, "the flat optimizer step serves the Trainer's own single parameter group"
             self._clip_and_update_flat()      # (divides by the all-reduced frame count itself when world > 1)
             return
         if self.world > 1:
