@@ -215,3 +215,32 @@ def test_enc_mid_hostsim(N, side):
 def test_bce_frames_hostsim(shape):
     import parity_cases
     parity_cases.bce_frames_vs_torch("cpu", *shape)
+
+
+@pytest.mark.parametrize("clip,wd,div", [(0.5, 0.0, None), (0.0, 1e-2, None), (10.0, 1e-3, 37.0)])
+def test_clip_adam_c_abi_vs_torch(hostsim_backend, clip, wd, div):
+    """kvae_clip_adam through the C ABI (host twin of the two GPU launches) against clip_grad_norm_ + torch.optim.Adam on the same
+    flat buffers: three steps, optional weight decay, optional division by a frame count (the multi-rank path)."""
+    from kvae import _native as N
+    g = torch.Generator().manual_seed(3)
+    n = 1000
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-3, weight_decay=wd)
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    step, norm, ws = torch.zeros(()), torch.zeros(()), torch.empty(1024)
+    cnt = torch.tensor([div]) if div else None
+    for it in range(3):
+        grad = torch.randn(n, generator=g) * (it + 1)
+        gref = grad / div if div else grad.clone()
+        ref.grad = gref.clone()
+        total = torch.nn.utils.clip_grad_norm_([ref], clip) if clip > 0 else gref.norm()
+        opt.step()
+        rc = hostsim_backend.dll.kvae_clip_adam(N.ptr(p), N.ptr(grad), N.ptr(m), N.ptr(v), n, None, 3e-3, N.ptr(step), 0.9, 0.999, 1e-8,
+                                               wd, clip, N.ptr(cnt) if cnt is not None else None, N.ptr(norm), N.ptr(ws), None)
+        assert rc == 0
+        assert abs(float(norm) - float(total)) <= 1e-5 * float(total)
+    assert float(step) == 3.0
+    assert float((p - ref.detach()).abs().max()) < 2e-6
+    st = opt.state[ref]
+    assert rel_err(m, st["exp_avg"]) < 1e-5 and rel_err(v, st["exp_avg_sq"]) < 5e-5   # (v squares the clip scale: twice its rounding)
