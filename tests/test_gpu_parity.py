@@ -123,6 +123,15 @@ def test_vs_oracle_dense_shared_q(B, T, n):
     parity_cases.vs_oracle_random(DEV, B, T, n, n, 2, 2, dense_q=True)
 
 
+@pytest.mark.parametrize("B,T,K", [(17, 5, 1), (3, 10, 1), (4, 5, 1), (17, 12, 1), (17, 5, 3)])
+def test_single_mode_n16_vs_fp64_oracle(B, T, K):
+    """K = 1 at n = 16: the float32 torch tape is itself ~1e-2 from float64 there (found by a random sweep over shapes), so the
+    gradients are held to the float64 oracle instead; (17, 5, 3) shows the same sweep point is well conditioned with three modes."""
+    tape = parity_cases.grads_vs_fp64_oracle(DEV, B, T, 16, K)
+    if K == 3:
+        assert tape < 3e-3
+
+
 def test_n16_generic_fallback():
     parity_cases.n16_generic_fallback(DEV)
 

@@ -122,6 +122,12 @@ def test_vs_oracle_random_hostsim(B, T, n, m, p, K):
     parity_cases.vs_oracle_random("cpu", B, T, n, m, p, K)
 
 
+@pytest.mark.parametrize("B,T", [(17, 5), (3, 10)])
+def test_single_mode_n16_vs_fp64_oracle_hostsim(B, T):
+    import parity_cases
+    parity_cases.grads_vs_fp64_oracle("cpu", B, T, 16, 1)
+
+
 def test_linearity_hostsim():
     import parity_cases
     parity_cases.linearity("cpu", 16, 20)
