@@ -27,7 +27,30 @@ _FAST_PATH_NOTES = {
 }
 
 
+class _SideGradJoin(torch.autograd.Function):
+    """Identity on a_samples for the frame branch; its backward adds the gradient the LGSSM branch has already produced on the
+    side stream (`early_kf_backward`), after making the current stream wait for that stream."""
+
+    @staticmethod
+    def forward(ctx, a, holder):
+        ctx.holder = holder
+        return a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, g):
+        h = ctx.holder
+        torch.cuda.current_stream().wait_stream(h["side"])
+        ga = h["a_side"].grad
+        h.clear()
+        return (g if ga is None else g + ga), None
+
+
 class KVAE(nn.Module):
+    # Training-step schedule (addition over the reference; set by kvae.train.Trainer): the gradient of the LGSSM term w.r.t. the
+    # encodings and the dynamics parameters does not depend on the frame terms, so compute_loss() can run that branch's backward
+    # on the side stream right behind its forward; loss.backward() then only walks the frame branch and picks the result up.
+    early_kf_backward = False
+
     def __init__(self, config):
         super().__init__()
         if hasattr(config, "validate"):
@@ -103,17 +126,22 @@ class KVAE(nn.Module):
             u = torch.zeros(x.shape[0], x.shape[1], self.u_dim, device=x.device, dtype=x.dtype)
         self.kalman_filter.dyn_params.reset_state()
         side = self.lgssm_stream if (self.training and a_samples.is_cuda) else None
+        a_side = None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
+            a_lgssm = a_samples
+            if self.early_kf_backward and torch.is_grad_enabled() and a_samples.requires_grad:
+                a_side = a_lgssm = a_samples.detach().requires_grad_(True)
+                a_samples = _SideGradJoin.apply(a_samples, {"a_side": a_side, "side": side})
             with torch.cuda.stream(side):
-                smoothed = self.kalman_filter.smooth(a_samples, u, mask=mask)
+                smoothed = self.kalman_filter.smooth(a_lgssm, u, mask=mask)
         else:
             smoothed = self.kalman_filter.smooth(a_samples, u, mask=mask)
         (mus_smooth, Sigmas_smooth, mus_filt, Sigmas_filt, mus_pred, Sigmas_pred, A_list, B_list, C_list) = smoothed
         x_logits = self.decode_sequence(a_samples)
         return {
             "x_recon": self._to_pixels(x_logits) if with_recon else None, "x_logits": x_logits,
-            "a_samples": a_samples, "a_mu": a_mu, "a_var": a_var,
+            "a_samples": a_samples, "a_mu": a_mu, "a_var": a_var, "a_side": a_side,
             "mus_smooth": mus_smooth, "Sigmas_smooth": Sigmas_smooth,
             "mus_filt": mus_filt, "Sigmas_filt": Sigmas_filt,
             "mus_pred": mus_pred, "Sigmas_pred": Sigmas_pred,
@@ -134,7 +162,18 @@ class KVAE(nn.Module):
         x_mu = outputs["x_logits"] if outputs.get("x_logits") is not None else outputs["x_recon"]
         side = self.lgssm_stream if (self.training and a.is_cuda) else None
 
+        a_side = outputs.get("a_side")
+
         def kf_elbo():
+            if a_side is not None:   # early_kf_backward: value and gradients of the LGSSM term on the side stream, now
+                with torch.cuda.stream(side):
+                    v = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a_side, u, A_list, B_list,
+                                                C_list, mask=mask)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    v.backward(torch.full_like(v, -float(kf_weight)))   # d loss / d elbo_kf
+                torch.cuda.current_stream().wait_event(done)   # the value only; _SideGradJoin waits for the gradients
+                return v.detach()
             if side is None:
                 return self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a, u, A_list, B_list, C_list,
                                                mask=mask)
@@ -147,23 +186,39 @@ class KVAE(nn.Module):
         from kvae import _native
         import os
         head = os.environ.get("KVAE_LOSS_HEAD")
-        if ((head == "1" or (head is None and side is None)) and self.config.out_distr.lower() == "bernoulli"
+        if head is None and a_side is not None:
+            head = "2"
+        if ((head in ("1", "2") or (head is None and side is None)) and self.config.out_distr.lower() == "bernoulli"
                 and _native.fused_ok(x_mu) and x_mu.dtype == torch.float32
                 and x.dtype == torch.float32 and a.dtype == torch.float32 and not x.requires_grad):
-            # GPU path without the side stream: the two per-frame terms are one kernel each and the whole scalar head of
-            # the objective (masking, sums, normalisation, beta / scale / weights, sign) is ONE launch each way
-            # (csrc/vae_heads.h) instead of ~40 dependent element-wise launches: -33 us per step eager or in a serial graph.
-            # With the LGSSM chain captured on a side stream the same change makes the replayed graph 0.14 ms SLOWER (3.84 vs
-            # 3.70 ms; the thinner graph overlaps worse, not yet understood), so that mode keeps the torch ops.
+            # The two per-frame terms are one kernel each and the whole scalar head of the objective (masking, sums,
+            # normalisation, beta / scale / weights, sign) is ONE launch each way (csrc/vae_heads.h) instead of ~40 dependent
+            # element-wise launches.  With the LGSSM chain on a side stream and ONE backward, the ~40 launches were what gave
+            # that chain's backward its head start over the decoder's Winograd kernels (which leave no registers for a
+            # second kernel on their CUs): the fused head made the replayed graph slower.  With
+            # early_kf_backward the side chain no longer needs that head start and the frame terms take the fused head ("2").
             from kvae.vae.fused import BernoulliFrameLogLik, LatentReg, LossHead
             lpx = BernoulliFrameLogLik.apply(x_mu, x)
             regf = LatentReg.apply(a, a_mu, a_var)
-            elbo_kf = kf_elbo()
             mk = None if mask is None else mask.to(device=x.device, dtype=torch.float32).reshape(B, T)
-            loss, elbo_total, elbo_kf_v, vae_elbo, recon, reg = LossHead.apply(
-                lpx, regf, elbo_kf, mk, self.beta, self.config.scale_reconstruction, vae_weight, kf_weight)
-            out = {"loss": loss, "elbo_total": elbo_total, "elbo_kf": elbo_kf_v, "elbo_vae_total": vae_elbo,
-                   "recon": recon, "kl": reg}
+            if head == "2":
+                # frame terms only through the fused head (main stream, before the join); the LGSSM term joins with torch ops, so
+                # its gradient reaches the side stream without waiting for the head's backward
+                z = getattr(self, "_zero_kf", None)
+                if z is None or z.device != x.device:
+                    z = self._zero_kf = torch.zeros(1, device=x.device, dtype=torch.float32)
+                vae_loss_w, _, _, vae_elbo, recon, reg = LossHead.apply(
+                    lpx, regf, z, mk, self.beta, self.config.scale_reconstruction, vae_weight, 0.0)
+                elbo_kf = kf_elbo()
+                loss = vae_loss_w - kf_weight * elbo_kf
+                out = {"loss": loss, "elbo_total": -loss.detach(), "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
+                       "recon": recon, "kl": reg}
+            else:
+                elbo_kf = kf_elbo()
+                loss, elbo_total, elbo_kf_v, vae_elbo, recon, reg = LossHead.apply(
+                    lpx, regf, elbo_kf, mk, self.beta, self.config.scale_reconstruction, vae_weight, kf_weight)
+                out = {"loss": loss, "elbo_total": elbo_total, "elbo_kf": elbo_kf_v, "elbo_vae_total": vae_elbo,
+                       "recon": recon, "kl": reg}
         else:
             x_var = torch.tensor(self.config.noise_pixel_var, device=x.device, dtype=x_mu.dtype) \
                 if self.config.out_distr.lower() != "bernoulli" else None

@@ -71,6 +71,8 @@ class Trainer:
         if model.lgssm_stream is not None and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
             # gradients of the LGSSM parameters are produced on the side stream by design
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        # ... and runs its backward right behind its forward (KVAE.early_kf_backward), not when loss.backward() reaches it
+        model.early_kf_backward = model.lgssm_stream is not None and os.environ.get("KVAE_EARLY_KF_BWD", "1") != "0"
         self.graph_fb = self.graph_opt = None
         self.static_x = self.static_mask = None
         self.out = {}

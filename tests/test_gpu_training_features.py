@@ -226,3 +226,36 @@ def test_flat_clip_adam_equals_torch_adam(monkeypatch):
     assert max(abs(a - b) / b for a, b in zip(nf, nt)) < 1e-5 and nt[0] > 0.5          # the clip was active
     assert float((pf - pt).abs().max()) < 2e-6
     assert rel_err(mf, mt) < 1e-5 and rel_err(vf, vt) < 5e-5   # (the second moment squares the clip scale: twice its rounding)
+
+
+@pytest.mark.parametrize("kind", ["lstm", "switching"])
+def test_early_lgssm_backward_gives_the_same_step(kind, monkeypatch):
+    """KVAE.early_kf_backward (the LGSSM branch differentiated on the side stream right behind its forward, its gradient w.r.t.
+    the encodings handed to loss.backward() at the join) against the ordinary single backward: same loss, same flat gradient
+    after one captured step, same parameters after three - with an explicit mask, both dynamics models."""
+    from kvae import noise
+    from kvae.train.synthetic import bouncing_ball
+    from kvae.train.train import Trainer
+    B, T = 6, 9
+    x = bouncing_ball(B, T, 3).float().to(DEV)
+    mask = (torch.rand(B, T, generator=torch.Generator().manual_seed(3)) > 0.2).float().to(DEV)
+    nz = _noise(B, T, seed=12)
+
+    def run(early):
+        monkeypatch.setenv("KVAE_EARLY_KF_BWD", "1" if early else "0")
+        model = _model(kind, seed=6)
+        tr = Trainer(model, lr=3e-3, grad_clip_norm=10.0, use_graph=True)
+        assert model.lgssm_stream is not None and model.early_kf_backward is early
+        with noise.inject(**nz):
+            out = tr.step(x, mask)
+            loss1, kf1, grad1 = float(out["loss"]), float(out["elbo_kf"]), tr.flat_grad.detach().clone().cpu()
+            for _ in range(2):
+                tr.step(x, mask)
+        torch.cuda.synchronize()
+        return loss1, kf1, grad1, torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+
+    le, ke, ge, pe = run(True)
+    ll, kl, gl, pl = run(False)
+    assert abs(le - ll) <= 1e-6 * abs(ll) and abs(ke - kl) <= 1e-6 * abs(kl)
+    assert float(gl.abs().max()) > 0 and rel_err(ge, gl) < 1e-5
+    assert float((pe - pl).abs().max()) < 1e-4   # three Adam steps at lr 3e-3: rounding-level gradient differences move entries with near-zero gradient
