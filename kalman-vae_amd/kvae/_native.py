@@ -258,13 +258,23 @@ def colsum_pair(a, b):
     weight- and bias-gradient partials of one layer."""
     import torch
     a2, b2 = a.reshape(a.shape[0], -1).contiguous(), b.reshape(b.shape[0], -1).contiguous()
-    if any(p.shape[0] >= 1024 and p.shape[1] < 4096 for p in (a2, b2)) or a2.device != b2.device:
+    tall = [p.shape[0] >= 1024 and p.shape[1] < 4096 for p in (a2, b2)]
+    if a2.device != b2.device or tall[0] != tall[1] or (tall[0] and (a2.shape[0] != b2.shape[0] or a2.shape[0] % 64)):
         return colsum(a), colsum(b)
-    oa = torch.empty(a2.shape[1], device=a2.device, dtype=torch.float32)
-    ob = torch.empty(b2.shape[1], device=b2.device, dtype=torch.float32)
-    lib = lib_for(a2)
-    lib.check(lib.dll.kvae_colsum2(ptr(a2), ptr(oa), a2.shape[0], a2.shape[1], ptr(b2), ptr(ob), b2.shape[0], b2.shape[1],
-                                   stream_for(a2)), "kvae_colsum2")
+
+    def pair(x, y):
+        ox = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+        oy = torch.empty(y.shape[1], device=y.device, dtype=torch.float32)
+        lib = lib_for(x)
+        lib.check(lib.dll.kvae_colsum2(ptr(x), ptr(ox), x.shape[0], x.shape[1], ptr(y), ptr(oy), y.shape[0], y.shape[1],
+                                       stream_for(x)), "kvae_colsum2")
+        return ox, oy
+
+    if tall[0]:   # the two-pass folding of colsum(), both tensors per launch
+        rows = a2.shape[0]
+        fa, fb = pair(a2.view(64, (rows // 64) * a2.shape[1]), b2.view(64, (rows // 64) * b2.shape[1]))
+        a2, b2 = fa.view(rows // 64, a2.shape[1]), fb.view(rows // 64, b2.shape[1])
+    oa, ob = pair(a2, b2)
     return oa.view(a.shape[1:]), ob.view(b.shape[1:])
 
 

@@ -225,10 +225,13 @@ class LgssmElbo(torch.autograd.Function):
         ctx.chol_levels = levels
         LgssmElbo.last_chol_levels = levels   # device int32[2] (Sigma_s, Q_t): level of _safe_cholesky's ladder, 5 = diagonal
         ctx.mark_non_differentiable(per_term)
+        ctx.set_materialize_grads(False)
         return per_term.sum(), per_term
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
+        if g_total is None:
+            return (None,) * 15
         sink, need = ctx.sink, ctx.needs_input_grad
         s = g_total
         gp = sink.gpacked * s if sink.gpacked is not None else None

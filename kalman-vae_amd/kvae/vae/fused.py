@@ -355,6 +355,7 @@ class LossHead(torch.autograd.Function):
                                              float(kf_w), N.ptr(out), N.ptr(coef), lpx.numel(), N.stream_for(lpx)),
                   "kvae_loss_head_fwd")
         ctx.save_for_backward(coef, mask)
+        ctx.set_materialize_grads(False)   # five of the six outputs never carry a gradient: no zero fills for them
         ctx.kf_w, ctx.shape, ctx.kf_shape = float(kf_w), lpx.shape, elbo_kf.shape
         vals = out.unbind(0)
         ctx.mark_non_differentiable(*vals[1:])
@@ -362,6 +363,8 @@ class LossHead(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
+        if g_loss is None:
+            return (None,) * 8
         coef, mask = ctx.saved_tensors
         g = g_loss.reshape(1).contiguous()
         g_lpx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)

@@ -498,3 +498,17 @@ def vae_heads_vs_torch(DEV, N):
             assert rel_err(got.detach().cpu(), want.detach()) < 2e-5
         for got, want in zip(dev_in, ref_in):
             assert rel_err(got.grad.cpu(), want.grad) < 2e-5
+
+
+def colsum_pair_vs_torch(DEV):
+    """_native.colsum_pair: short partials (one launch), tall partials of equal height (two launches, both tensors folded
+    [64, rows/64 * cols] -> [rows/64, cols] in each) and unequal heights (two separate colsum calls) against torch's sum."""
+    from kvae import _native
+    g = torch.Generator().manual_seed(5)
+    for ra, ca, rb, cb in [(100, 36, 100, 4), (2048, 36, 2048, 4), (1024, 288, 1024, 32), (2048, 36, 1024, 4), (1088, 7, 1088, 3),
+                           (1030, 36, 1030, 4)]:
+        a, b = torch.randn(ra, ca, generator=g).to(DEV), torch.randn(rb, 2, cb // 2 if cb % 2 == 0 else cb, generator=g).to(DEV)
+        sa, sb = _native.colsum_pair(a, b)
+        assert sa.shape == a.shape[1:] and sb.shape == b.shape[1:]
+        assert rel_err(sa.cpu(), a.cpu().double().sum(0).float()) < 2e-6
+        assert rel_err(sb.cpu(), b.cpu().double().sum(0).float()) < 2e-6
