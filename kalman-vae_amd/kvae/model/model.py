@@ -163,6 +163,10 @@ class KVAE(nn.Module):
         side = self.lgssm_stream if (self.training and a.is_cuda) else None
 
         a_side = outputs.get("a_side")
+        stats = None
+        if with_metrics == "device":   # before the LGSSM term is awaited: the main stream has this to do while the side stream finishes
+            variances = a_mu.detach().reshape(-1, a_mu.shape[-1]).var(dim=0)
+            stats = ((variances > 1e-2).sum(), variances)
 
         def kf_elbo():
             if a_side is not None:   # early_kf_backward: value and gradients of the LGSSM term on the side stream, now
@@ -230,8 +234,7 @@ class KVAE(nn.Module):
             out = {"loss": -elbo_total, "elbo_total": elbo_total, "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
                    "recon": recon, "kl": reg}
         if with_metrics == "device":
-            variances = a_mu.detach().reshape(-1, a_mu.shape[-1]).var(dim=0)
-            out.update(active_units=(variances > 1e-2).sum(), latent_variances=variances)
+            out.update(active_units=stats[0], latent_variances=stats[1])
         elif with_metrics:
             active, variances = count_active_units(a_mu)
             out.update(active_units=active, latent_var_0=variances[0].item(), latent_var_1=variances[1].item())
