@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 8
+#define KVAE_ABI_VERSION 9
 
 typedef enum {
   KVAE_OK = 0,
@@ -300,6 +300,11 @@ int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *ou
 int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const float *g_out, float *g_x, float *w_partials,
                     float *b_partials, int64_t N, int32_t Cin, int32_t side, void *stream);
 int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side);
+/* The decoder blocks run as persistent workgroups, one per CU (256).  A caller that overlaps them with a second stream whose
+ * kernels cannot share a CU with them (kvae/train/train.py: the LGSSM chain of the switching model) may ask for fewer, which
+ * leaves CUs free while they run; partial_rows follows.  n outside [1, 256] restores the default; returns the previous value.
+ * Process-wide: set it around the launches (or the graph capture) it is meant for.  No reference counterpart. */
+int32_t kvae_dec_up_set_workgroups(int32_t n);
 
 /* ---- skinny fully-connected ends of the frame VAE and the latent regulariser --------------- */
 

@@ -1037,12 +1037,25 @@ static bool dec_up_wino() {
   static const int env = getenv("KVAE_WINO") ? atoi(getenv("KVAE_WINO")) : 1;   // 0: direct convolution (A/B runs)
   return env != 0;
 }
+// Persistent decoder-block workgroups: one per CU, or fewer (KVAE_UP_WGS) so that a second stream's kernels that do not fit
+// beside them (anything above 32 registers per lane) find free CUs while they run.
+static int g_dec_up_wgs = 0;   // 0: not set through kvae_dec_up_set_workgroups
+static inline int64_t dec_up_cap() {
+  static const int env = getenv("KVAE_UP_WGS") ? atoi(getenv("KVAE_UP_WGS")) : 0;   // the environment wins over the setter (A/B runs)
+  const int v = env >= 1 && env <= 256 ? env : __atomic_load_n(&g_dec_up_wgs, __ATOMIC_RELAXED);
+  return v >= 1 && v <= 256 ? v : 256;
+}
 static inline int64_t dec_up_grid(int64_t N, int32_t side) {
-  const int64_t fpi = side == 8 ? 2 : 8, iters = (N + fpi - 1) / fpi;
-  return iters < 256 ? (iters < 1 ? 1 : iters) : 256;   // one persistent workgroup per CU
+  const int64_t fpi = side == 8 ? 2 : 8, iters = (N + fpi - 1) / fpi, cap = dec_up_cap();
+  return iters < cap ? (iters < 1 ? 1 : iters) : cap;
 }
 extern "C" {
 int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side) { return dec_up_grid(N, side); }
+int32_t kvae_dec_up_set_workgroups(int32_t n) {
+  const int32_t prev = (int32_t)dec_up_cap();
+  __atomic_store_n(&g_dec_up_wgs, n >= 1 && n <= 256 ? n : 0, __ATOMIC_RELAXED);
+  return prev;
+}
 
 int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cin, int32_t side,
                     void *stream) {
@@ -1052,7 +1065,7 @@ int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *ou
   const dim3 grid((unsigned)dec_up_grid(N, side));
   if (dec_up_wino()) {   // pairs of workgroups (one per half of the output channels) walk the column sets together
     const int64_t sets = side == 8 ? N : (N + 3) / 4;
-    const dim3 wgrid((unsigned)(sets < 256 ? sets : 256));
+    const dim3 wgrid((unsigned)(sets < dec_up_cap() ? sets : dec_up_cap()));
     static const int pm = getenv("KVAE_WINO_PM") ? atoi(getenv("KVAE_WINO_PM")) : 1;   // 0: k-step-major MFMA order (A/B runs)
     if (side == 8 && pm) k_dec_up_fwd_wino<8, true><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
     else if (side == 8) k_dec_up_fwd_wino<8, false><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
@@ -1072,7 +1085,7 @@ int kvae_dec_up_bwd(const float *x, const float *W, const float *out, const floa
   const dim3 grid((unsigned)dec_up_grid(N, side));
   if (g_x) {
     const int64_t sets = side == 8 ? N : (N + 3) / 4;
-    const dim3 wgrid((unsigned)(sets < 256 ? sets : 256));
+    const dim3 wgrid((unsigned)(sets < dec_up_cap() ? sets : dec_up_cap()));
     if (dec_up_wino() && side == 8) k_dec_up_bwd_data_wino<8><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
     else if (dec_up_wino()) k_dec_up_bwd_data_wino<4><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);
     else if (side == 8) k_dec_up_bwd_data<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(W, out, g_out, g_x, N);

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -50,7 +50,7 @@ SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_alpha_lstm_bwd", "kvae_lg
            "kvae_lstm_bwd", "kvae_bias_shuffle_act_fwd", "kvae_bias_shuffle_act_bwd", "kvae_bias_partial_rows", "kvae_colsum", "kvae_colsum2", "kvae_clip_adam", "kvae_regime_fwd", "kvae_regime_bwd", "kvae_bigru_fwd", "kvae_bigru_bwd", "kvae_bce_frames_fwd", "kvae_bce_frames_bwd",
            "kvae_dec_head_fwd", "kvae_dec_head_bwd", "kvae_enc_stem_fwd", "kvae_enc_stem_bwd", "kvae_conv_edge_partial_rows",
            "kvae_enc_mid_fwd", "kvae_enc_mid_bwd", "kvae_enc_mid_partial_rows",
-           "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows",
+           "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows", "kvae_dec_up_set_workgroups",
            "kvae_enc_head_fwd", "kvae_enc_head_bwd", "kvae_dec_fc_fwd", "kvae_dec_fc_bwd", "kvae_head_partial_rows",
            "kvae_latent_reg_fwd", "kvae_latent_reg_bwd", "kvae_loss_head_fwd", "kvae_loss_head_bwd",
            "kvae_abi_version",
@@ -142,6 +142,8 @@ class LgssmLib:
         d.kvae_loss_head_bwd.argtypes = [vp, vp, vp, C.c_float, vp, vp, vp, C.c_int64, vp]
         d.kvae_loss_head_bwd.restype = C.c_int
         d.kvae_dec_up_partial_rows.restype = C.c_int64
+        d.kvae_dec_up_set_workgroups.argtypes = [C.c_int32]
+        d.kvae_dec_up_set_workgroups.restype = C.c_int32
         d.kvae_enc_mid_partial_rows.restype = C.c_int64
         d.kvae_conv_edge_partial_rows.argtypes = [C.c_int64]
         d.kvae_conv_edge_partial_rows.restype = C.c_int64

@@ -245,7 +245,27 @@ class Trainer:
                 else:
                     v.zero_()      # state created by the warm-up: back to a fresh optimizer (step 0, zero moments), in place
 
+    def _decoder_workgroups(self, batch):
+        """Persistent decoder-block workgroups for the captured step.  The switching model's side chain (bi-GRU, regime chain,
+        LGSSM, all above the 32 registers per lane the Winograd workgroups leave free) is what the encoder's backward waits
+        for; with 32 of the 256 CUs left to it the step is 7 % shorter at 256 sequences (3.08 -> 2.86 ms, a step at exactly
+        224: 228 gives 3.10), whereas the lstm model's chain is hidden anyway and every CU taken from the decoder costs
+        (2.73 / 2.76 / 2.80 ms at 256 / 248 / 240).  Larger batches hide the chain behind a longer frame pass: full width."""
+        dyn = self.model.kalman_filter.dyn_params
+        if self.model.lgssm_stream is not None and getattr(dyn, "is_switching_dynamics", False) and batch <= 256:
+            return 224
+        return 256
+
     def _capture(self, x, mask=None):
+        from .. import _native
+        lib = _native.lib_for(x)
+        prev = lib.dll.kvae_dec_up_set_workgroups(self._decoder_workgroups(x.shape[0]))
+        try:
+            self._capture_graphs(x, mask)
+        finally:   # process-wide setting: only the launches recorded above are meant
+            lib.dll.kvae_dec_up_set_workgroups(prev if prev != 256 else 0)
+
+    def _capture_graphs(self, x, mask=None):
         try:
             torch.backends.cuda.preferred_blas_library("cublas")   # == rocBLAS on ROCm (see module header)
         except Exception:

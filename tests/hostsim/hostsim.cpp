@@ -523,11 +523,17 @@ int kvae_enc_mid_bwd(const float *in, const float *W, const float *out, const fl
 
 // Decoder up-sampling blocks (conv 32 -> 128, 3x3 pad 1, PixelShuffle(2), ReLU): plain loops, same argument checks.
 extern "C" {
+static int g_dec_up_wgs_sim = 256;
 static int64_t dec_up_grid_sim(int64_t N, int32_t side) {
   const int64_t fpi = side == 8 ? 2 : 8, iters = (N + fpi - 1) / fpi;
-  return iters < 256 ? (iters < 1 ? 1 : iters) : 256;
+  return iters < g_dec_up_wgs_sim ? (iters < 1 ? 1 : iters) : g_dec_up_wgs_sim;
 }
 int64_t kvae_dec_up_partial_rows(int64_t N, int32_t side) { return dec_up_grid_sim(N, side); }
+int32_t kvae_dec_up_set_workgroups(int32_t n) {
+  const int32_t prev = g_dec_up_wgs_sim;
+  g_dec_up_wgs_sim = n >= 1 && n <= 256 ? n : 256;
+  return prev;
+}
 
 int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *out, int64_t N, int32_t Cin, int32_t side,
                     void *) {

@@ -512,3 +512,19 @@ def colsum_pair_vs_torch(DEV):
         assert sa.shape == a.shape[1:] and sb.shape == b.shape[1:]
         assert rel_err(sa.cpu(), a.cpu().double().sum(0).float()) < 2e-6
         assert rel_err(sb.cpu(), b.cpu().double().sum(0).float()) < 2e-6
+
+
+def dec_up_workgroup_cap(DEV):
+    """kvae_dec_up_set_workgroups: fewer persistent workgroups than column sets (a stride loop with a ragged last round, fewer
+    rows of weight-gradient partials) give the same block as the default; the previous value comes back and 0 restores it."""
+    from kvae import _native
+    lib = _native.lib_for(torch.zeros(1, device=DEV))
+    default = lib.dll.kvae_dec_up_set_workgroups(7)
+    try:
+        assert lib.dll.kvae_dec_up_partial_rows(100, 8) == 7 and lib.dll.kvae_dec_up_partial_rows(5, 4) == 1
+        dec_up_vs_torch(DEV, 100, 8)
+        dec_up_vs_torch(DEV, 45, 4)
+        assert lib.dll.kvae_dec_up_set_workgroups(1000) == 7   # out of range: back to the default
+        assert lib.dll.kvae_dec_up_partial_rows(12800, 8) == 256
+    finally:
+        lib.dll.kvae_dec_up_set_workgroups(0 if default == 256 else default)

@@ -132,6 +132,10 @@ def test_single_mode_n16_vs_fp64_oracle(B, T, K):
         assert tape < 3e-3
 
 
+def test_dec_up_workgroup_cap():
+    parity_cases.dec_up_workgroup_cap(DEV)
+
+
 def test_colsum_pair():
     parity_cases.colsum_pair_vs_torch(DEV)
 

@@ -128,6 +128,11 @@ def test_single_mode_n16_vs_fp64_oracle_hostsim(B, T):
     parity_cases.grads_vs_fp64_oracle("cpu", B, T, 16, 1)
 
 
+def test_dec_up_workgroup_cap_hostsim():
+    import parity_cases
+    parity_cases.dec_up_workgroup_cap("cpu")
+
+
 def test_colsum_pair_hostsim():
     import parity_cases
     parity_cases.colsum_pair_vs_torch("cpu")

@@ -9,6 +9,7 @@ import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--replays", type=int, default=50)
+ap.add_argument("--dynamics", default="lstm")
 args = ap.parse_args()
 import bench
 from kvae.model import model as M
@@ -16,7 +17,7 @@ from kvae.train.synthetic import bouncing_ball
 from kvae.train.train import Trainer
 
 dev = torch.device("cuda:0")
-bargs = argparse.Namespace(dynamics="lstm", modes=3, z_dim=4)
+bargs = argparse.Namespace(dynamics=args.dynamics, modes=3, z_dim=4)
 cfg, model = bench.build_model(bargs, dev)
 x = bouncing_ball(256, 50, 1234).float().to(dev)
 events = {}
