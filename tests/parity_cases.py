@@ -219,13 +219,14 @@ def linearity(DEV, B=256, T=50):
 
 
 
-def safe_cholesky_levels(DEV, n=4):
+def safe_cholesky_levels(DEV, n=4, B=2, T=4):
     """_safe_cholesky semantics: one bad Q_t forces the WHOLE batch up the jitter ladder / to the diagonal
     fallback, exactly like the oracle (kalman_filter.py:282-302).  n = 16: the matrix-core ELBO kernels resolve the
-    level in their probe and hand levels > 0 to the generic main kernel on the device."""
+    level in their probe and hand levels > 0 to the generic main kernel on the device; (B, T) = (40, 10): more steps than
+    one round of wavefronts of the four-steps-per-wavefront launch, ragged."""
     from kvae.kalman.lgssm_ops import LgssmElbo, Slots
     from oracle import c_oracle
-    B, T, m, p = 2, 4, n, 2
+    m, p = n, 2
     A, Bm, Cm, alpha, Y, U, mask, eps = _random_problem(B, T, n, m, p, 1, 5, DEV)
     R = 0.03 * torch.eye(p, device=DEV)
     mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)

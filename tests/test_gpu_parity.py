@@ -156,9 +156,9 @@ def test_linearity_full_size():
     parity_cases.linearity(DEV, 256, 50)
 
 
-@pytest.mark.parametrize("n", [4, 16])
-def test_safe_cholesky_levels(n):
-    parity_cases.safe_cholesky_levels(DEV, n)
+@pytest.mark.parametrize("n,B,T", [(4, 2, 4), (16, 2, 4), (16, 40, 10)])
+def test_safe_cholesky_levels(n, B, T):
+    parity_cases.safe_cholesky_levels(DEV, n, B, T)
 
 
 @pytest.mark.parametrize("name,levels", JITTER_CASES)
