@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define KVAE_MAX_DIM 16
-#define KVAE_ABI_VERSION 9
+#define KVAE_ABI_VERSION 10
 
 typedef enum {
   KVAE_OK = 0,
@@ -240,14 +240,55 @@ int kvae_colsum2(const float *partials_a, float *out_a, int64_t rows_a, int64_t 
 /* One training step's tail on four flat fp32 buffers of n elements (parameters, gradients, Adam's exp_avg and exp_avg_sq):
  *   g <- g / max(*div_dev, 1)  (div_dev may be NULL: the multi-rank frame count);  total = ||g||_2  -> *norm_out (may be NULL);
  *   g <- g * min(1, clip / (total + 1e-6))  if clip > 0   (torch.nn.utils.clip_grad_norm_);
- *   *step_dev += 1;  Adam exactly as torch's fused kernel computes it (L2 weight decay added to g, exp_avg lerp,
+ *   step += 1;  Adam exactly as torch's fused kernel computes it (L2 weight decay added to g, exp_avg lerp,
  *   step_size = lr / (1 - beta1^step), denom = sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).
+ * Segments = parameter tensors: seg_of[i] in [0, n_seg) names the tensor of element i (NULL: one segment, n_seg == 1);
+ * seg_steps[n_seg] are the per-parameter step counts torch's Adam keeps; seg_active[n_seg] (NULL: all active) is 0 for a FROZEN
+ * parameter - requires_grad False in the reference's training phases (train.py:142-207), i.e. .grad is None: it does not enter
+ * the norm, and neither its moments, its step count nor its values change, exactly as clip_grad_norm_ and Adam skip it.
  * lr is read from *lr_dev when given (a device scalar follows the LR schedule under hipGraph replay), else from `lr`.
- * The gradient buffer is left unscaled (it is overwritten by the next step).  ws: >= 1024 floats.  Two launches, fixed
- * summation order. */
-int kvae_clip_adam(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr_dev,
-                   float lr, float *step_dev, float beta1, float beta2, float eps, float weight_decay, float clip,
-                   const float *div_dev, float *norm_out, float *ws, void *stream);
+ * The gradient buffer is left unscaled (it is overwritten by the next step).  ws: >= 1024 floats; n_seg <= 1024.  Two launches,
+ * fixed summation order. */
+int kvae_clip_adam(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const int32_t *seg_of,
+                   int32_t n_seg, const float *seg_active, float *seg_steps, const float *lr_dev, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float clip, const float *div_dev, float *norm_out, float *ws, void *stream);
+
+/* ---- imputation read-out (kvae/model/model.py:279-288) --------------------------------------------------- */
+
+/* a_imputed[b,t,:] = C_t mu_{t|T},  a_filtered[b,t,:] = C_t mu_{t|t}  (both [B,T,p]; either output may be NULL together with its
+ * input) with C_t the emission stack of the problem `prob` the means came from: what KVAE.impute decodes.  Only prob->B, T, n,
+ * p and prob->C are read. */
+int kvae_lgssm_emission_means(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *mus_filt, float *a_imputed,
+                              float *a_filtered, void *stream);
+
+/* ---- parameter gradients of the alpha-network recurrences and the linear heads (no library GEMM on the path) ---- */
+
+/* G[r][c] = sum_q d[q][r] * X[q][c] over the N = B*T rows, X[q] = [ h[q + shift] (H columns; zero when step t + shift leaves
+ * the sequence) | x[q] (I columns) | 1 (when bias) ]: dW_hh | dW_ih | db of nn.LSTM / one nn.GRU direction from the d_pre rows
+ * its BPTT kernel wrote (the autograd of kvae/kalman/dyn_param.py:50-56 and switch_dyn_param.py:113-129 in the reference), or
+ * dW | db of a linear head (shift 0).  Outputs (each may be NULL): g_wh [R,H], g_wx [R,I], g_b [R].  R <= 256,
+ * H + I + bias <= 256, N a multiple of T. */
+typedef struct kvae_wgrad_problem {
+  const float *d;            /* [N,R], row stride d_stride (floats) */
+  const float *h;            /* hidden sequence, row stride h_stride; NULL when H == 0 */
+  const float *x;            /* inputs, row stride x_stride; NULL when I == 0 */
+  float *g_wh, *g_wx, *g_b;
+  int64_t d_stride, h_stride, x_stride, N;
+  int32_t R, H, I, bias, T, shift;   /* shift: -1 = h_{t-1}, +1 = h_{t+1} (reverse direction), 0 = h_t */
+} kvae_wgrad_problem;
+/* Up to four problems in ONE pair of launches (f32 matrix cores, split over the rows; a second launch sums the partials in a
+ * fixed order).  ws: kvae_rnn_wgrad_ws_floats(probs, n) floats. */
+int64_t kvae_rnn_wgrad_ws_floats(const kvae_wgrad_problem *probs, int32_t n);
+int kvae_rnn_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, void *stream);
+
+/* y[N,O] = x[N,F] W[O,F]^T + b (b may be NULL); softmax != 0: softmax over the O <= 16 outputs fused (head_w + softmax,
+ * dyn_param.py:53-56).  x rows are x_stride floats apart.  F <= 128, O*F <= 16384. */
+int kvae_linear_fwd(const float *x, int64_t x_stride, int64_t N, int32_t F, const float *W, const float *b, int32_t O,
+                    int32_t softmax, float *y, void *stream);
+/* dx[N,F] = gl W with gl = g, or - when y (the softmax output of the forward) is given - gl = y * (g - <g, y>), which is then
+ * also written to g_logit [N,O] (the rows kvae_rnn_wgrad reduces to dW, db).  dx rows are dx_stride floats apart. */
+int kvae_linear_bwd_input(const float *g, const float *y, int64_t N, int32_t F, const float *W, int32_t O, float *g_logit,
+                          float *dx, int64_t dx_stride, void *stream);
 
 /* ---- fused Bernoulli reconstruction term of the frame VAE --------------------------------- */
 
@@ -333,11 +374,13 @@ int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const
 /* The scalar head of the objective (kvae/vae/losses.py:45-69, kvae/model/model.py:214-232) over n = B*T frames:
  * recon = sum(lpx*mk)/denom, reg = sum(regf*mk)/denom, denom = max(sum mk, 1) (mask NULL = all ones);
  * out6 = (loss, elbo_total, elbo_kf, vae_elbo, recon, reg), loss = -(vae_weight*(scale*recon + beta*reg) + kf_weight*elbo_kf);
- * coef2 = per-frame d loss/d lpx, d loss/d regf (for the backward).  elbo_kf, beta: device scalars. */
+ * coef3 = per-frame d loss/d lpx, d loss/d regf, and kf_weight (for the backward).  elbo_kf, beta: device scalars.
+ * weights_dev (may be NULL): device scalars (vae_weight, kf_weight) that replace the by-value weights - the reference's training
+ * phases change kf_weight between epochs (train.py:246-260) and a step captured into a hipGraph follows the device values. */
 int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, const float *elbo_kf, const float *beta,
-                       float scale_reconstruction, float vae_weight, float kf_weight, float *out6, float *coef2, int64_t n,
-                       void *stream);
-int kvae_loss_head_bwd(const float *g_loss, const float *coef2, const float *mask, float kf_weight, float *g_lpx, float *g_regf,
+                       float scale_reconstruction, float vae_weight, float kf_weight, const float *weights_dev, float *out6,
+                       float *coef3, int64_t n, void *stream);
+int kvae_loss_head_bwd(const float *g_loss, const float *coef3, const float *mask, float *g_lpx, float *g_regf,
                        float *g_elbo_kf, int64_t n, void *stream);
 
 /* ---- misc --------------------------------------------------------------------------------- */

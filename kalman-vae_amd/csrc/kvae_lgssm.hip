@@ -513,6 +513,68 @@ int kvae_lstm_bwd(const float *g_h, const float *gates, const float *c_seq, cons
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
+// imputation read-out: a = C_t mu_t for the smoothed and the filtered means in one launch (model.py:279-288)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emission_means(kvae_stack C, const float *__restrict__ ms, const float *__restrict__ mf,
+                                                        float *__restrict__ a_s, float *__restrict__ a_f, int64_t BT, int T, int n,
+                                                        int p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= BT * p) return;
+  const int64_t q = idx / p;
+  const int i = (int)(idx % p);
+  const float *c = C.ptr + (q / T) * C.sb + (q % T) * C.st + (int64_t)i * n;
+  float s = 0.f, f = 0.f;
+  for (int k = 0; k < n; ++k) {
+    const float ck = c[k];
+    if (ms) s = fmaf(ck, ms[q * n + k], s);
+    if (mf) f = fmaf(ck, mf[q * n + k], f);
+  }
+  if (a_s) a_s[idx] = s;
+  if (a_f) a_f[idx] = f;
+}
+extern "C" int kvae_lgssm_emission_means(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *mus_filt,
+                                         float *a_imputed, float *a_filtered, void *stream) {
+  if (!prob || !prob->C.ptr || (!mus_smooth != !a_imputed) || (!mus_filt != !a_filtered) || (!a_imputed && !a_filtered))
+    return KVAE_ERR_NULL;
+  if (prob->B < 1 || prob->T < 1 || prob->n < 1 || prob->p < 1 || prob->n > KVAE_MAX_DIM || prob->p > KVAE_MAX_DIM) return KVAE_ERR_DIMS;
+  const int64_t BT = (int64_t)prob->B * prob->T;
+  k_emission_means<<<dim3((unsigned)((BT * prob->p + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      prob->C, mus_smooth, mus_filt, a_imputed, a_filtered, BT, prob->T, prob->n, prob->p);
+  return launch_status("k_emission_means");
+}
+
+// ---------------------------------------------------------------------------------------------
+// alpha-network parameter gradients and linear heads (kvae_lgssm_rnn.hip)
+// ---------------------------------------------------------------------------------------------
+extern "C" int kvae_rnn_launch_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, hipStream_t s);
+extern "C" int kvae_rnn_launch_linear_fwd(const float *x, int64_t xs, int64_t N, int F, const float *W, const float *b, int O,
+                                          int softmax, float *y, hipStream_t s);
+extern "C" int kvae_rnn_launch_linear_bwd_input(const float *g, const float *y, int64_t N, int F, const float *W, int O,
+                                                float *g_logit, float *dx, int64_t dxs, hipStream_t s);
+extern "C" {
+int kvae_rnn_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, void *stream) {
+  if (!probs || !ws) return KVAE_ERR_NULL;
+  if (n < 1 || n > 4) return KVAE_ERR_ARG;
+  const int rc = kvae_rnn_launch_wgrad(probs, n, ws, (hipStream_t)stream);
+  return rc ? rc : launch_status("k_rnn_wgrad");
+}
+int kvae_linear_fwd(const float *x, int64_t x_stride, int64_t N, int32_t F, const float *W, const float *b, int32_t O,
+                    int32_t softmax, float *y, void *stream) {
+  if (!x || !W || !y) return KVAE_ERR_NULL;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (softmax && O > 16)) return KVAE_ERR_DIMS;
+  kvae_rnn_launch_linear_fwd(x, x_stride, N, F, W, b, O, softmax, y, (hipStream_t)stream);
+  return launch_status("k_linear_fwd");
+}
+int kvae_linear_bwd_input(const float *g, const float *y, int64_t N, int32_t F, const float *W, int32_t O, float *g_logit,
+                          float *dx, int64_t dx_stride, void *stream) {
+  if (!g || !W || !dx || (y && !g_logit)) return KVAE_ERR_NULL;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (y && O > 16)) return KVAE_ERR_DIMS;
+  kvae_rnn_launch_linear_bwd_input(g, y, N, F, W, O, g_logit, dx, dx_stride, (hipStream_t)stream);
+  return launch_status("k_linear_bwd_input");
+}
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
 // fused conv epilogues of the frame VAE (vae_epilogue.h)
 // ---------------------------------------------------------------------------------------------
 #include "vae_epilogue.h"
@@ -736,13 +798,22 @@ int64_t kvae_bias_partial_rows(int64_t N) { return (N + KVAE_EPI_SAMPLES_PER_CHU
 // clip_grad_norm_ + Adam on flat buffers: two launches instead of ~12 (norm, clamp, reciprocal, scale, three foreach kernels)
 // ---------------------------------------------------------------------------------------------
 constexpr int CA_BLOCKS = 512;   // partial sums of squares (ws[0..CA_BLOCKS))
-__global__ __launch_bounds__(256) void k_grad_sumsq(const float *__restrict__ g, int64_t n, const float *__restrict__ div_dev,
-                                                    float *__restrict__ step_dev, float *__restrict__ ws) {
+constexpr int CA_MAX_SEG = 1024;  // parameter tensors ("segments") of one flat buffer
+// Segments: seg_of[i] names the parameter tensor element i belongs to; a segment with seg_active[s] == 0 is a FROZEN parameter
+// (requires_grad False: the reference's training phases, train.py:142-207) - torch's clip_grad_norm_ and Adam skip it because its
+// .grad is None: it adds nothing to the norm, its moments and its step count stay as they are.  Every segment counts its own steps
+// (torch keeps `step` per parameter, so a parameter thawed at epoch 6 starts its bias correction at step 1).
+__global__ __launch_bounds__(256) void k_grad_sumsq(const float *__restrict__ g, int64_t n, const int32_t *__restrict__ seg_of,
+                                                    int n_seg, const float *__restrict__ seg_active,
+                                                    const float *__restrict__ div_dev, float *__restrict__ seg_steps,
+                                                    float *__restrict__ ws) {
   __shared__ float red[256];
   const float inv = div_dev ? 1.0f / fmaxf(*div_dev, 1.0f) : 1.0f;
+  const bool gated = seg_of && seg_active;
   float s = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float v = g[i] * inv;
+    float v = g[i] * inv;
+    if (gated && seg_active[seg_of[i]] == 0.f) v = 0.f;
     s = fmaf(v, v, s);
   }
   red[threadIdx.x] = s;
@@ -751,20 +822,29 @@ __global__ __launch_bounds__(256) void k_grad_sumsq(const float *__restrict__ g,
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    ws[blockIdx.x] = red[0];
-    if (blockIdx.x == 0) *step_dev += 1.0f;          // the next launch reads the incremented step
-  }
+  if (threadIdx.x == 0) ws[blockIdx.x] = red[0];
+  if (blockIdx.x == 0)                                  // the next launch reads the incremented step counts
+    for (int sg = threadIdx.x; sg < n_seg; sg += 256)
+      if (!seg_active || seg_active[sg] != 0.f) seg_steps[sg] += 1.0f;
 }
 __global__ __launch_bounds__(256) void k_clip_adam(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, int64_t n, const float *__restrict__ lr_dev, float lr,
-                                                   const float *__restrict__ step_dev, float beta1, float beta2, float eps,
+                                                   float *__restrict__ v, int64_t n, const int32_t *__restrict__ seg_of, int n_seg,
+                                                   const float *__restrict__ seg_active, const float *__restrict__ seg_steps,
+                                                   const float *__restrict__ lr_dev, float lr, float beta1, float beta2, float eps,
                                                    float wd, float clip, const float *__restrict__ div_dev,
                                                    float *__restrict__ norm_out, const float *__restrict__ ws, int nparts) {
   __shared__ float red[256];
+  __shared__ float s_step_size[CA_MAX_SEG], s_bc2s[CA_MAX_SEG];   // step_size < 0 marks a frozen segment
   float s = 0.f;                                      // every block folds the same partials in the same order
   for (int i = threadIdx.x; i < nparts; i += 256) s += ws[i];
   red[threadIdx.x] = s;
+  const float lrv = lr_dev ? *lr_dev : lr;
+  for (int sg = threadIdx.x; sg < n_seg; sg += 256) {
+    const float step = seg_steps[sg];
+    const bool on = !seg_active || seg_active[sg] != 0.f;
+    s_step_size[sg] = on ? lrv / (1.0f - powf(beta1, step)) : -1.0f;
+    s_bc2s[sg] = on ? sqrtf(1.0f - powf(beta2, step)) : 1.0f;
+  }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -774,10 +854,10 @@ __global__ __launch_bounds__(256) void k_clip_adam(float *__restrict__ p, const 
   if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total;
   const float inv = div_dev ? 1.0f / fmaxf(*div_dev, 1.0f) : 1.0f;
   const float scale = inv * (clip > 0.f ? fminf(clip / (total + 1e-6f), 1.0f) : 1.0f);
-  const float step = *step_dev, lrv = lr_dev ? *lr_dev : lr;
-  const float bc1 = 1.0f - powf(beta1, step), bc2s = sqrtf(1.0f - powf(beta2, step));
-  const float step_size = lrv / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int sg = seg_of ? seg_of[i] : 0;
+    const float step_size = s_step_size[sg], bc2s = s_bc2s[sg];
+    if (step_size < 0.f) continue;
     float gi = g[i] * scale;
     const float pi = p[i];
     if (wd != 0.f) gi = fmaf(wd, pi, gi);
@@ -787,19 +867,21 @@ __global__ __launch_bounds__(256) void k_clip_adam(float *__restrict__ p, const 
     p[i] = pi - step_size * mi / (sqrtf(vi) / bc2s + eps);
   }
 }
-extern "C" int kvae_clip_adam(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr_dev,
-                              float lr, float *step_dev, float beta1, float beta2, float eps, float weight_decay, float clip,
-                              const float *div_dev, float *norm_out, float *ws, void *stream) {
-  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_dev || !ws) return KVAE_ERR_NULL;
-  if (n < 1) return KVAE_ERR_ARG;
+extern "C" int kvae_clip_adam(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                              const int32_t *seg_of, int32_t n_seg, const float *seg_active, float *seg_steps, const float *lr_dev,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float clip, const float *div_dev,
+                              float *norm_out, float *ws, void *stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !seg_steps || !ws) return KVAE_ERR_NULL;
+  if (n < 1 || n_seg < 1 || n_seg > CA_MAX_SEG || (!seg_of && n_seg != 1)) return KVAE_ERR_ARG;
   const int64_t want = (n + 1023) / 1024;
   const unsigned parts = (unsigned)(want < CA_BLOCKS ? want : CA_BLOCKS);
-  k_grad_sumsq<<<dim3(parts), dim3(256), 0, (hipStream_t)stream>>>(grads, n, div_dev, step_dev, ws);
+  k_grad_sumsq<<<dim3(parts), dim3(256), 0, (hipStream_t)stream>>>(grads, n, seg_of, n_seg, seg_active, div_dev, seg_steps, ws);
   int rc = launch_status("k_grad_sumsq");
   if (rc) return rc;
   const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  k_clip_adam<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, lr_dev, lr, step_dev, beta1,
-                                                                   beta2, eps, weight_decay, clip, div_dev, norm_out, ws, (int)parts);
+  k_clip_adam<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, seg_of, n_seg, seg_active,
+                                                                   seg_steps, lr_dev, lr, beta1, beta2, eps, weight_decay, clip,
+                                                                   div_dev, norm_out, ws, (int)parts);
   return launch_status("k_clip_adam");
 }
 
@@ -1157,19 +1239,19 @@ int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const
   return launch_status("k_latent_reg_bwd");
 }
 int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, const float *elbo_kf, const float *beta,
-                       float scale_reconstruction, float vae_weight, float kf_weight, float *out6, float *coef2, int64_t n,
-                       void *stream) {
-  if (!lpx || !regf || !elbo_kf || !beta || !out6 || !coef2) return KVAE_ERR_NULL;
+                       float scale_reconstruction, float vae_weight, float kf_weight, const float *weights_dev, float *out6,
+                       float *coef3, int64_t n, void *stream) {
+  if (!lpx || !regf || !elbo_kf || !beta || !out6 || !coef3) return KVAE_ERR_NULL;
   if (n < 1) return KVAE_ERR_ARG;
   k_loss_head_fwd<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(lpx, regf, mask, elbo_kf, beta, scale_reconstruction, vae_weight,
-                                                                  kf_weight, out6, coef2, n);
+                                                                  kf_weight, weights_dev, out6, coef3, n);
   return launch_status("k_loss_head_fwd");
 }
-int kvae_loss_head_bwd(const float *g_loss, const float *coef2, const float *mask, float kf_weight, float *g_lpx, float *g_regf,
+int kvae_loss_head_bwd(const float *g_loss, const float *coef3, const float *mask, float *g_lpx, float *g_regf,
                        float *g_elbo_kf, int64_t n, void *stream) {
-  if (!g_loss || !coef2 || !g_lpx || !g_regf || !g_elbo_kf) return KVAE_ERR_NULL;
+  if (!g_loss || !coef3 || !g_lpx || !g_regf || !g_elbo_kf) return KVAE_ERR_NULL;
   if (n < 1) return KVAE_ERR_ARG;
-  k_loss_head_bwd<<<dim3(epi_grid(n)), dim3(256), 0, (hipStream_t)stream>>>(g_loss, coef2, mask, kf_weight, g_lpx, g_regf,
+  k_loss_head_bwd<<<dim3(epi_grid(n)), dim3(256), 0, (hipStream_t)stream>>>(g_loss, coef3, mask, g_lpx, g_regf,
                                                                             g_elbo_kf, n);
   return launch_status("k_loss_head_bwd");
 }

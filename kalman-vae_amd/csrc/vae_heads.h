@@ -190,13 +190,16 @@ __global__ __launch_bounds__(256) void k_latent_reg_bwd(const float *__restrict_
 // The scalar head of the objective (reference kvae/vae/losses.py:45-69 and kvae/model/model.py:214-232) in ONE launch:
 //   recon = sum(lpx * mk) / denom, reg = sum(regf * mk) / denom, denom = max(sum mk, 1)
 //   vae_elbo = scale * recon + beta * reg;  elbo_total = vae_w * vae_elbo + kf_w * elbo_kf;  loss = -elbo_total
-// out[6] = (loss, elbo_total, elbo_kf, vae_elbo, recon, reg); coef[2] = d loss / d lpx, d loss / d regf per observed frame.
+// out[6] = (loss, elbo_total, elbo_kf, vae_elbo, recon, reg); coef[3] = d loss / d lpx, d loss / d regf per observed frame, kf_w.
+// w_dev (may be NULL) = device scalars (vae_w, kf_w) that override the by-value weights: the reference's phases move kf_weight
+// between epochs (train.py:246-260) and a captured step has to follow.
 // As torch ops this is ~25 dependent launches of a few microseconds each (and ~17 more in the backward), all on the
 // critical path between the decoder's forward and backward.
 __global__ __launch_bounds__(1024) void k_loss_head_fwd(const float *__restrict__ lpx, const float *__restrict__ regf,
                                                         const float *__restrict__ mask, const float *__restrict__ elbo_kf,
                                                         const float *__restrict__ beta, float scale, float vae_w, float kf_w,
-                                                        float *__restrict__ out, float *__restrict__ coef, int64_t n) {
+                                                        const float *__restrict__ w_dev, float *__restrict__ out,
+                                                        float *__restrict__ coef, int64_t n) {
   // one block of 1024 threads, dwordx4 loads: a handful of memory round trips in total (a narrower block turns the
   // reduction into a 50-deep chain of dependent global loads, slower than the launches it replaces)
   __shared__ float red[3][1024];
@@ -232,16 +235,18 @@ __global__ __launch_bounds__(1024) void k_loss_head_fwd(const float *__restrict_
   }
   if (threadIdx.x == 0) {
     const float denom = fmaxf(red[2][0], 1.f), b = beta[0], kf = elbo_kf[0];
+    if (w_dev) vae_w = w_dev[0], kf_w = w_dev[1];
     const float recon = red[0][0] / denom, reg = red[1][0] / denom;
     const float vae = scale * recon + b * reg, tot = vae_w * vae + kf_w * kf;
     out[0] = -tot; out[1] = tot; out[2] = kf; out[3] = vae; out[4] = recon; out[5] = reg;
     coef[0] = -vae_w * scale / denom;
     coef[1] = -vae_w * b / denom;
+    coef[2] = kf_w;
   }
 }
-// g_lpx = g * coef[0] * mk, g_regf = g * coef[1] * mk, g_kf = -kf_w * g   (g = upstream gradient of the loss)
+// g_lpx = g * coef[0] * mk, g_regf = g * coef[1] * mk, g_kf = -coef[2] * g   (g = upstream gradient of the loss)
 __global__ __launch_bounds__(256) void k_loss_head_bwd(const float *__restrict__ g, const float *__restrict__ coef,
-                                                       const float *__restrict__ mask, float kf_w, float *__restrict__ g_lpx,
+                                                       const float *__restrict__ mask, float *__restrict__ g_lpx,
                                                        float *__restrict__ g_regf, float *__restrict__ g_kf, int64_t n) {
   const float gg = g[0], c0 = gg * coef[0], c1 = gg * coef[1];
   const float *msrc = mask ? mask : g_lpx;   // always a valid address, value selected afterwards (see k_loss_head_fwd)
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void k_loss_head_bwd(const float *__restrict__
     g_lpx[i] = c0 * mk;
     g_regf[i] = c1 * mk;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) g_kf[0] = -kf_w * gg;
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_kf[0] = -coef[2] * gg;
 }
 
 }  // namespace kvae

@@ -17,7 +17,7 @@ LIB_PATH = _HERE / "lib" / "libkvae_lgssm.so"
 KVAE_MAX_DIM = 16
 KVAE_MAX_K = 16
 LSTM_MAX_H, LSTM_MAX_I = 52, 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _STATUS = {1: "KVAE_ERR_DIMS (n, m, p must be in [1,16]; B, T >= 1)", 2: "KVAE_ERR_NULL", 3: "KVAE_ERR_LAUNCH",
            4: "KVAE_ERR_ARG"}
@@ -40,6 +40,12 @@ class States(C.Structure):  # kvae_lgssm_states
                                           "mus_smooth", "Sigmas_smooth", "aux")]
 
 
+class WgradProblem(C.Structure):  # kvae_wgrad_problem
+    _fields_ = [("d", C.c_void_p), ("h", C.c_void_p), ("x", C.c_void_p), ("g_wh", C.c_void_p), ("g_wx", C.c_void_p),
+                ("g_b", C.c_void_p), ("d_stride", C.c_int64), ("h_stride", C.c_int64), ("x_stride", C.c_int64), ("N", C.c_int64),
+                ("R", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("bias", C.c_int32), ("T", C.c_int32), ("shift", C.c_int32)]
+
+
 class InputGrads(C.Structure):  # kvae_lgssm_input_grads
     _fields_ = [("gA", Stack), ("gB", Stack), ("gC", Stack), ("gQ", Stack),
                 ("gY", C.c_void_p), ("gU", C.c_void_p), ("g_mu0", C.c_void_p), ("g_Sigma0", C.c_void_p)]
@@ -53,6 +59,7 @@ SYMBOLS = ("kvae_lgssm_filter_alpha_lstm", "kvae_lgssm_alpha_lstm_bwd", "kvae_lg
            "kvae_dec_up_fwd", "kvae_dec_up_bwd", "kvae_dec_up_partial_rows", "kvae_dec_up_set_workgroups",
            "kvae_enc_head_fwd", "kvae_enc_head_bwd", "kvae_dec_fc_fwd", "kvae_dec_fc_bwd", "kvae_head_partial_rows",
            "kvae_latent_reg_fwd", "kvae_latent_reg_bwd", "kvae_loss_head_fwd", "kvae_loss_head_bwd",
+           "kvae_lgssm_emission_means", "kvae_rnn_wgrad", "kvae_rnn_wgrad_ws_floats", "kvae_linear_fwd", "kvae_linear_bwd_input",
            "kvae_abi_version",
            "kvae_last_error", "kvae_build_info")
 
@@ -137,9 +144,9 @@ class LgssmLib:
         d.kvae_latent_reg_fwd.restype = C.c_int
         d.kvae_latent_reg_bwd.argtypes = [vp] * 7 + [C.c_int64, C.c_int32, vp]
         d.kvae_latent_reg_bwd.restype = C.c_int
-        d.kvae_loss_head_fwd.argtypes = [vp] * 5 + [C.c_float] * 3 + [vp, vp, C.c_int64, vp]
+        d.kvae_loss_head_fwd.argtypes = [vp] * 5 + [C.c_float] * 3 + [vp, vp, vp, C.c_int64, vp]
         d.kvae_loss_head_fwd.restype = C.c_int
-        d.kvae_loss_head_bwd.argtypes = [vp, vp, vp, C.c_float, vp, vp, vp, C.c_int64, vp]
+        d.kvae_loss_head_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, vp]
         d.kvae_loss_head_bwd.restype = C.c_int
         d.kvae_dec_up_partial_rows.restype = C.c_int64
         d.kvae_dec_up_set_workgroups.argtypes = [C.c_int32]
@@ -151,8 +158,18 @@ class LgssmLib:
         d.kvae_colsum.restype = C.c_int
         d.kvae_colsum2.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int64, C.c_int64, vp]
         d.kvae_colsum2.restype = C.c_int
-        d.kvae_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_float, vp, C.c_float, C.c_float, C.c_float, C.c_float,
-                                     C.c_float, vp, vp, vp, vp]
+        d.kvae_lgssm_emission_means.argtypes = [P, vp, vp, vp, vp, vp]
+        d.kvae_lgssm_emission_means.restype = C.c_int
+        d.kvae_rnn_wgrad_ws_floats.argtypes = [C.POINTER(WgradProblem), C.c_int32]
+        d.kvae_rnn_wgrad_ws_floats.restype = C.c_int64
+        d.kvae_rnn_wgrad.argtypes = [C.POINTER(WgradProblem), C.c_int32, vp, vp]
+        d.kvae_rnn_wgrad.restype = C.c_int
+        d.kvae_linear_fwd.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp]
+        d.kvae_linear_fwd.restype = C.c_int
+        d.kvae_linear_bwd_input.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, C.c_int32, vp, vp, C.c_int64, vp]
+        d.kvae_linear_bwd_input.restype = C.c_int
+        d.kvae_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int32, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, vp, vp, vp, vp]
         d.kvae_clip_adam.restype = C.c_int
         d.kvae_bias_partial_rows.argtypes = [C.c_int64]
         d.kvae_bias_partial_rows.restype = C.c_int64

@@ -3,7 +3,7 @@
 Same constructor, parameters and state_dict keys as the reference's DynamicsParameter
 (kvae/kalman/dyn_param.py:5-63): A[K,n,n], B[K,n,m], C[K,p,n], lstm.*, head_w.*.
 On a HIP device the recurrence is hand-written HIP: `kvae_lstm_fwd/bwd` for a fully observed sequence (the whole T loop
-in one launch; the three weight gradients are small rocBLAS GEMMs on its d_pre output) and, when a mask is given, the
+in one launch; the three weight gradients are one `kvae_rnn_wgrad` reduction over its d_pre output) and, when a mask is given, the
 cell runs INSIDE the filter kernel (`kvae_lgssm_filter_alpha_lstm` / `kvae_lgssm_alpha_lstm_bwd`, kalman_filter.py here).
 The mixing A_t = sum_k alpha_tk A_k (dyn_param.py:58-60) is `kvae_mix_fwd/bwd` and yields one packed step record.
 Hidden sizes above 52 fall back to nn.LSTM (MIOpen), which cannot be captured into a hipGraph.
@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native
-from .lgssm_ops import LstmSequence, Slots, mix_dynamics
+from .lgssm_ops import LstmSequence, Slots, mix_dynamics, small_linear
 
 
 class DynamicsParameter(nn.Module):
@@ -41,7 +41,7 @@ class DynamicsParameter(nn.Module):
     def alpha_sequence(self, a_seq):
         """alpha[B,T,K] for a fully observed sequence: the LSTM input at step t is a_{t-1} (zeros at
         t = 0), exactly what the reference's per-step loop feeds it when mask == 1
-        (kalman_filter.py:142,183-185); one batched MIOpen call instead of T cell launches."""
+        (kalman_filter.py:142,183-185); one HIP launch for the whole recurrence instead of T cell launches."""
         Bsz, T, _ = a_seq.shape
         if self.K == 1:
             return torch.ones(Bsz, T, 1, device=a_seq.device, dtype=a_seq.dtype)
@@ -53,7 +53,7 @@ class DynamicsParameter(nn.Module):
             self.lstm_state = None
         else:  # hidden sizes beyond the LDS-resident kernel: PyTorch-ROCm (MIOpen) recurrence
             h, self.lstm_state = self.lstm(shifted, None)
-        return torch.softmax(self.head_w(h), dim=-1)
+        return small_linear(h, self.head_w, softmax=True)   # head + softmax: one launch each way on a HIP device
 
     def step_record(self, alpha):
         """(record [B,T,E], Slots) with A|B|C mixed by alpha [B,T,K] (K > 1)."""

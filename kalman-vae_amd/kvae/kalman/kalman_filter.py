@@ -177,6 +177,13 @@ class KalmanFilter(nn.Module):
         ms, Ss, mf, Sf, mp, Sp = self._run(Y, U, mask, with_rts=True)
         return (ms, Ss, mf, Sf, mp, Sp) + tuple(self._last["views"])
 
+    def emission_means(self, mus_smooth, mus_filt, C_list):
+        """(C_t mu_t|T, C_t mu_t|t): the two latent read-outs KVAE.impute decodes (reference model.py:279-288), one launch."""
+        last = self._last
+        if last is not None and C_list is last["views"][2] and last["slots"].C is not None:
+            return lgssm_ops.emission_means(mus_smooth, mus_filt, C_list, last["rec"], last["slots"].C)
+        return lgssm_ops.emission_means(mus_smooth, mus_filt, C_list)
+
     # ------------------------------------------------------------------------------------------
     # ELBO
     # ------------------------------------------------------------------------------------------

@@ -1,10 +1,9 @@
 """torch.autograd bridge to the HIP LGSSM kernels (C ABI: include/kvae_lgssm.h).
 
 PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd graph.
-Every numerical step of filter / RTS smoother / ELBO / mixing / recurrences — forward and backward — runs in
-libkvae_lgssm.so, with two exceptions that stay torch ops on the same stream: the weight gradients of the LSTM / bi-GRU
-/ head are plain GEMMs (rocBLAS) over the d_pre / g_logit tensors the BPTT kernels write, and trivial reductions
-(`terms.sum`).  Nothing computes on the host.
+Every numerical step of filter / RTS smoother / ELBO / mixing / recurrences / linear heads — forward and backward,
+including the weight gradients of the LSTM / bi-GRU / heads (`kvae_rnn_wgrad`: no library GEMM on the path) — runs in
+libkvae_lgssm.so; only trivial reductions (`terms.sum`) stay torch ops on the same stream.  Nothing computes on the host.
 
 Per-step operands (A_t, B_t, C_t, Q_t) reach the kernels as strided "stacks": either slots of ONE
 packed record tensor [B,T,E] produced by `mix_dynamics` (mixture-of-K case: a single launch writes
@@ -289,11 +288,95 @@ def mix_dynamics(alpha, mats):
 
 
 # ------------------------------------------------------------------------------------------------
+# parameter gradients of the recurrences and heads (csrc/rnn_wgrad.h), linear heads (csrc/small_linear.h)
+# ------------------------------------------------------------------------------------------------
+def rnn_wgrad(ref, problems):
+    """Up to four reductions G = D^T [h_shifted | x | 1] over the (sequence, step) rows in one pair of launches.
+    problems: dicts with d [N,R]; optional h (2-D view, unit column stride) with `shift` and `T`; optional x [N,I]; `bias`.
+    Returns one (g_wh [R,H] | None, g_wx [R,I] | None, g_b [R] | None) per problem."""
+    lib = N.lib_for(ref)
+    arr = (N.WgradProblem * len(problems))()
+    outs, keep = [], []
+    for slot, pr in zip(arr, problems):
+        d, h, x = pr["d"], pr.get("h"), pr.get("x")
+        n_rows, R = d.shape
+        assert d.stride(1) == 1 and (h is None or h.stride(1) == 1) and (x is None or x.stride(1) == 1)
+        H, I, bias = (h.shape[1] if h is not None else 0), (x.shape[1] if x is not None else 0), int(bool(pr.get("bias", True)))
+        g_wh = torch.empty(R, H, device=d.device, dtype=torch.float32) if H else None
+        g_wx = torch.empty(R, I, device=d.device, dtype=torch.float32) if I else None
+        g_b = torch.empty(R, device=d.device, dtype=torch.float32) if bias else None
+        slot.d, slot.h, slot.x = d.data_ptr(), (h.data_ptr() if H else None), (x.data_ptr() if I else None)
+        slot.g_wh, slot.g_wx, slot.g_b = (t.data_ptr() if t is not None else None for t in (g_wh, g_wx, g_b))
+        slot.d_stride, slot.h_stride, slot.x_stride = d.stride(0), (h.stride(0) if H else 0), (x.stride(0) if I else 0)
+        slot.N, slot.R, slot.H, slot.I, slot.bias = n_rows, R, H, I, bias
+        slot.T, slot.shift = int(pr.get("T", 1)), int(pr.get("shift", 0))
+        outs.append((g_wh, g_wx, g_b))
+        keep += [d, h, x]
+    ws = torch.empty(int(lib.dll.kvae_rnn_wgrad_ws_floats(arr, len(problems))), device=ref.device, dtype=torch.float32)
+    lib.check(N.timed("rnn_wgrad", ref, lambda: lib.dll.kvae_rnn_wgrad(arr, len(problems), N.ptr(ws), N.stream_for(ref))),
+              "kvae_rnn_wgrad")
+    return outs
+
+
+def small_linear_supported(x, weight, softmax=False):
+    O, F = weight.shape
+    return (N.fused_ok(x) and x.dtype == torch.float32 and weight.dtype == torch.float32 and F <= 128 and O * F <= 16384
+            and (not softmax or O <= 16) and x.shape[-1] == F and x.stride(-1) == 1
+            and (x.dim() == 2 or x.is_contiguous()))
+
+
+class SmallLinear(torch.autograd.Function):
+    """y = x W^T + b (optionally followed by a softmax over the outputs) for the heads of the alpha-networks
+    (reference dyn_param.py:53-56: head_w + softmax; switch_dyn_param.py:119-129: linear_head / init_head): one launch
+    forward, one for the input gradient, and the rnn_wgrad reduction for dW | db - instead of addmm / softmax / two GEMMs /
+    a column sum from the BLAS library.  x: [..., F] contiguous, or a 2-D view with unit column stride (h_seq[:, 0])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, softmax):
+        w, b = _f32c(weight), _f32c(bias)
+        O, F = w.shape
+        x2 = x if x.dim() == 2 else x.reshape(-1, F)
+        y = torch.empty(x2.shape[0], O, device=x.device, dtype=torch.float32)
+        lib = N.lib_for(x)
+        lib.check(N.timed("linear_fwd", x, lambda: lib.dll.kvae_linear_fwd(
+            N.ptr(x2), x2.stride(0), x2.shape[0], F, N.ptr(w), N.ptr(b), O, int(softmax), N.ptr(y), N.stream_for(x))), "kvae_linear_fwd")
+        ctx.softmax, ctx.lead = bool(softmax), x.shape[:-1]
+        ctx.save_for_backward(x2, w, y if softmax else None)
+        return y.reshape(*x.shape[:-1], O)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, y = ctx.saved_tensors
+        O, F = w.shape
+        g2 = _f32c(g).reshape(-1, O)
+        lib = N.lib_for(g2)
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = gl = None
+        if need_x or ctx.softmax:
+            dx = torch.empty(x2.shape[0], F, device=g2.device, dtype=torch.float32)
+            gl = torch.empty_like(g2) if ctx.softmax else None
+            lib.check(N.timed("linear_bwd", g2, lambda: lib.dll.kvae_linear_bwd_input(
+                N.ptr(g2), N.ptr(y), x2.shape[0], F, N.ptr(w), O, N.ptr(gl), N.ptr(dx), F, N.stream_for(g2))), "kvae_linear_bwd_input")
+        g_w = g_b = None
+        if need_w or need_b:
+            (g_w, _, g_b), = rnn_wgrad(g2, [dict(d=gl if ctx.softmax else g2, h=x2, bias=True)])
+        return (dx.reshape(*ctx.lead, F) if need_x else None), g_w, g_b, None
+
+
+def small_linear(x, linear, softmax=False):
+    """nn.Linear `linear` (+ softmax) through SmallLinear when the shapes fit the kernels, else through torch."""
+    if small_linear_supported(x, linear.weight, softmax):
+        return SmallLinear.apply(x, linear.weight, linear.bias, softmax)
+    y = linear(x)
+    return torch.softmax(y, dim=-1) if softmax else y
+
+
+# ------------------------------------------------------------------------------------------------
 # alpha-network LSTM
 # ------------------------------------------------------------------------------------------------
 class LstmSequence(torch.autograd.Function):
     """h_seq = LSTM(x) from a zero state (single layer, batch_first, torch gate order): the HIP replacement
-    for stepping nn.LSTM T times (reference dyn_param.py:50-52).  Backward: one BPTT launch + three GEMMs."""
+    for stepping nn.LSTM T times (reference dyn_param.py:50-52).  Backward: one BPTT launch + the rnn_wgrad reduction."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
@@ -321,11 +404,10 @@ class LstmSequence(torch.autograd.Function):
         lib.check(N.timed("lstm_bwd", x, lambda: lib.dll.kvae_lstm_bwd(
             N.ptr(g_h), N.ptr(gates), N.ptr(c), N.ptr(w_ih), N.ptr(w_hh), N.ptr(d_pre), N.ptr(dx),
             Bsz, T, I, H, N.stream_for(x))), "kvae_lstm_bwd")
-        d2 = d_pre.reshape(Bsz * T, 4 * H)
-        h_prev = torch.cat([h.new_zeros(Bsz, 1, H), h[:, :-1]], dim=1).reshape(Bsz * T, H)
-        g_whh = d2.t() @ h_prev
-        g_wih = d2.t() @ x.reshape(Bsz * T, I)
-        g_b = N.colsum(d2)
+        if not any(ctx.needs_input_grad[1:]):   # frozen alpha-network ("vae" / "warmup" phase): the input gradient only
+            return dx, None, None, None, None
+        (g_whh, g_wih, g_b), = rnn_wgrad(x, [dict(d=d_pre.reshape(Bsz * T, 4 * H), h=h.reshape(Bsz * T, H), shift=-1, T=T,
+                                                  x=x.reshape(Bsz * T, I))])
         return dx, g_wih, g_whh, g_b, g_b
 
 
@@ -379,7 +461,7 @@ def _ptr2(a, b):
 
 class BiGruSequence(torch.autograd.Function):
     """h_seq [B,T,2H] = nn.GRU(bidirectional, batch_first)(x) from zero states (reference switch_dyn_param.py:118,123):
-    one launch for both directions forward, one BPTT launch backward, parameter gradients as GEMMs."""
+    one launch for both directions forward, one BPTT launch backward, all eight parameter gradients in one rnn_wgrad call."""
     SUPPORTED = (50, 2)   # (hidden, input): the shape csrc/gru_fast.h is instantiated for
 
     @staticmethod
@@ -409,13 +491,18 @@ class BiGruSequence(torch.autograd.Function):
         lib.check(N.timed("bigru_bwd", x, lambda: lib.dll.kvae_bigru_bwd(
             N.ptr(g_h), N.ptr(gates), N.ptr(h), _ptr2(wi0, wi1), _ptr2(wh0, wh1), N.ptr(dpi), N.ptr(dph), N.ptr(dx),
             Bsz, T, I, H, N.stream_for(x))), "kvae_bigru_bwd")
-        x2 = x.reshape(Bsz * T, I)
-        zero = h.new_zeros(Bsz, 1, H)
-        hp = (torch.cat([zero, h[:, :-1, :H]], 1), torch.cat([h[:, 1:, H:], zero], 1))   # h_{prev} per direction
+        if not any(ctx.needs_input_grad[1:]):   # frozen regime posterior: the input gradient only
+            return (dx.sum(0),) + (None,) * 8
+        x2, h2 = x.reshape(Bsz * T, I), h.reshape(Bsz * T, 2 * H)
+        probs = []
+        for d in (0, 1):   # h_prev of the forward direction is h_{t-1}, of the reverse direction h_{t+1}
+            probs.append(dict(d=dpi[d].reshape(Bsz * T, 3 * H), x=x2))
+            probs.append(dict(d=dph[d].reshape(Bsz * T, 3 * H), h=h2[:, d * H:(d + 1) * H], shift=-1 if d == 0 else 1, T=T))
+        res = rnn_wgrad(x, probs)
         out = [dx.sum(0)]
         for d in (0, 1):
-            di, dh = dpi[d].reshape(Bsz * T, 3 * H), dph[d].reshape(Bsz * T, 3 * H)
-            out += [di.t() @ x2, dh.t() @ hp[d].reshape(Bsz * T, H), N.colsum(di), N.colsum(dh)]
+            (_, g_wih, g_bih), (g_whh, _, g_bhh) = res[2 * d], res[2 * d + 1]
+            out += [g_wih, g_whh, g_bih, g_bhh]
         return tuple(out)
 
 
@@ -497,12 +584,13 @@ class AlphaLstmSmooth(torch.autograd.Function):
             C.byref(call.prob), C.byref(saved), C.byref(up), C.byref(sink.g), N.ptr(ws), int(with_rts), N.ptr(w_ih), N.ptr(w_hh),
             N.ptr(head_w), N.ptr(A), N.ptr(Bm), N.ptr(Cm), K, H, N.ptr(alpha), N.ptr(gates), N.ptr(c_seq), N.ptr(g_rec),
             N.ptr(g_alpha), N.ptr(sink.gpacked), N.ptr(d_pre), N.ptr(g_logit), call.stream)), "kvae_lgssm_alpha_lstm_bwd")
-        # parameter gradients: reductions over (b,t) of what the launch wrote
-        d2 = d_pre.reshape(Bsz * T, 4 * H)
-        h_prev = torch.cat([h_seq.new_zeros(Bsz, 1, H), h_seq[:, :-1]], dim=1).reshape(Bsz * T, H)
-        g_whh, g_wih, g_b = d2.t() @ h_prev, d2.t() @ x_seq.reshape(Bsz * T, p), N.colsum(d2)
-        gl2 = g_logit.reshape(Bsz * T, K)
-        g_hw, g_hb = gl2.t() @ h_seq.reshape(Bsz * T, H), N.colsum(gl2)
+        # parameter gradients: reductions over (b,t) of what the launch wrote (none for a frozen alpha-network)
+        g_whh = g_wih = g_b = g_hw = g_hb = None
+        if any(need[3:9]):
+            h2 = h_seq.reshape(Bsz * T, H)
+            (g_whh, g_wih, g_b), (g_hw, _, g_hb) = rnn_wgrad(Y, [
+                dict(d=d_pre.reshape(Bsz * T, 4 * H), h=h2, shift=-1, T=T, x=x_seq.reshape(Bsz * T, p)),
+                dict(d=g_logit.reshape(Bsz * T, K), h=h2)])
         base = torch.cat([t.reshape(K, -1) for t in (A, Bm, Cm)], dim=1)
         nblk = call.lib.dll.kvae_mix_bwd_partials(Bsz * T)
         E = base.shape[1]
@@ -511,12 +599,30 @@ class AlphaLstmSmooth(torch.autograd.Function):
         call.lib.check(call.lib.dll.kvae_mix_bwd(N.ptr(alpha), N.ptr(base), N.ptr(sink.gpacked), N.ptr(g_alpha_scratch), N.ptr(g_base),
                                                  N.ptr(partials), Bsz * T, K, E, 0, call.stream), "kvae_mix_bwd")
         gA, gB, gC = g_base.split([n * n, n * m, p * n], dim=1)
+        gA, gB, gC = (g.reshape(t.shape) if nd else None for g, t, nd in zip((gA, gB, gC), (A, Bm, Cm), need[9:12]))
         if g0 is not None and mu0.dim() == 1:
             g0 = N.colsum(g0)
         if S0 is not None and Sigma0.dim() == 2:
             S0 = N.colsum(S0)
         return (sink.gY if need[0] else None, sink.gU if need[1] else None, None, g_wih, g_whh, g_b, g_b, g_hw, g_hb,
-                gA.reshape(A.shape), gB.reshape(Bm.shape), gC.reshape(Cm.shape), None, None, g0, S0, None)
+                gA, gB, gC, None, None, g0, S0, None)
+
+
+@torch.no_grad()
+def emission_means(mus_smooth, mus_filt, C_view, packed=None, c_off=None):
+    """(C_t mu_t|T, C_t mu_t|t) [B,T,p] in one launch (reference model.py:279-288).  C_view: the [B,T,p,n] emission stack the
+    caller holds (may be an expanded [p,n] or a slice of the packed step record `packed` at float offset `c_off`)."""
+    ms, mf = _f32c(mus_smooth.squeeze(-1)), _f32c(mus_filt.squeeze(-1))
+    Bsz, T, n = ms.shape
+    p = C_view.shape[-2]
+    prob = N.Problem()
+    prob.B, prob.T, prob.n, prob.m, prob.p = Bsz, T, n, n, p
+    keep, prob.C = _stack(C_view, Bsz, T, p, n, packed, c_off)
+    a_s, a_f = torch.empty(Bsz, T, p, device=ms.device, dtype=torch.float32), torch.empty(Bsz, T, p, device=ms.device, dtype=torch.float32)
+    lib = N.lib_for(ms)
+    lib.check(lib.dll.kvae_lgssm_emission_means(C.byref(prob), N.ptr(ms), N.ptr(mf), N.ptr(a_s), N.ptr(a_f), N.stream_for(ms)),
+              "kvae_lgssm_emission_means")
+    return a_s, a_f
 
 
 @torch.no_grad()

@@ -3,9 +3,9 @@ regime samples, a sticky Markov prior, and regime-mixed A_t, B_t, Q_t.
 
 Same classes, constructor signatures and state_dict keys as the reference
 (kvae/kalman/switch_dyn_param.py:7-129).  On a HIP device with the default shapes (hidden 50, input 2) the bi-GRU
-recurrence is the hand-written `kvae_bigru_fwd/bwd` kernel (its weight gradients are three small rocBLAS GEMMs),
+recurrence is the hand-written `kvae_bigru_fwd/bwd` kernel (its weight gradients: one `kvae_rnn_wgrad` call),
 the Gumbel-softmax regime chain is `kvae_regime_fwd/bwd`, and the mixing einsums (switch_dyn_param.py:82-84) are
-`kvae_mix_fwd/bwd` producing one packed A|B|Q step record; the two linear heads stay torch ops.  Other GRU shapes
+`kvae_mix_fwd/bwd` producing one packed A|B|Q step record; the two linear heads are `kvae_linear_fwd/bwd_input`.  Other GRU shapes
 take nn.GRU (MIOpen).  Gumbel noise can be injected (kvae.noise.inject) for parity tests.
 """
 import torch
@@ -14,7 +14,7 @@ from torch.distributions import Multinomial
 
 from .. import noise
 from .. import _native
-from .lgssm_ops import BiGruSequence, RegimeChain, Slots, mix_dynamics
+from .lgssm_ops import BiGruSequence, RegimeChain, Slots, mix_dynamics, small_linear
 
 
 def _gumbel_softmax(logits, g, tau, hard):
@@ -170,5 +170,5 @@ class MarkovVariationalRegimePosterior(nn.Module):
                                         g.bias_hh_l0_reverse)
         else:   # other shapes / host tensors: PyTorch (MIOpen) GRU
             h_seq, _ = self.bigru(a_seq)
-        logits = self.linear_head(h_seq).unflatten(-1, (self.K, self.K))
-        return logits, self.init_head(h_seq[:, 0])
+        logits = small_linear(h_seq, self.linear_head).unflatten(-1, (self.K, self.K))
+        return logits, small_linear(h_seq[:, 0], self.init_head)

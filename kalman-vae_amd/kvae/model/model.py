@@ -6,10 +6,12 @@ signatures and output dictionaries.  For the reference's default shapes every la
 hand-written HIP kernels of csrc/vae_*.h (kvae/vae/fused.py; other shapes: MIOpen + fused epilogues), and everything
 between `a_samples` and the LGSSM ELBO runs in the HIP kernels behind `self.kalman_filter`.
 """
+import os
+
 import torch
 from torch import nn
 
-from kvae import noise
+from kvae import _native, noise
 from kvae.kalman import dyn_param as base_dyn_param
 from kvae.kalman import switch_dyn_param
 from kvae.kalman.kalman_filter import KalmanFilter
@@ -41,15 +43,28 @@ class _SideGradJoin(torch.autograd.Function):
         h = ctx.holder
         torch.cuda.current_stream().wait_stream(h["side"])
         ga = h["a_side"].grad
-        h.clear()
-        return (g if ga is None else g + ga), None
+        if ga is None:   # the frame branch is being differentiated but nobody ran the LGSSM branch's backward
+            raise RuntimeError("KVAE.early_kf_backward is on but the LGSSM branch has no gradient yet: call "
+                               "compute_loss() (which runs that branch's backward) before loss.backward(), or clear the flag")
+        return g + ga, None
+
+
+# A/B switch for the scalar head of the objective, read ONCE (None: chosen per call from the step's schedule):
+# 2 = frame terms through the fused head, 1 = LGSSM term too, 0 = torch's element-wise ops.
+_LOSS_HEAD = os.environ.get("KVAE_LOSS_HEAD")
 
 
 class KVAE(nn.Module):
     # Training-step schedule (addition over the reference; set by kvae.train.Trainer): the gradient of the LGSSM term w.r.t. the
     # encodings and the dynamics parameters does not depend on the frame terms, so compute_loss() can run that branch's backward
     # on the side stream right behind its forward; loss.backward() then only walks the frame branch and picks the result up.
+    # The Trainer sets these three for the duration of its own forward+backward only (Trainer._schedule) and restores them:
+    # a training-mode forward / compute_loss / backward outside a Trainer always takes the plain single-backward route.
     early_kf_backward = False
+    lgssm_stream = None     # second HIP stream for the LGSSM chain: it is latency-bound (256 of ~8000 wave slots at configs[1])
+    #                         and independent of the decoder, so it overlaps with the decoder convolutions; compute_loss() joins
+    kf_value_only = False   # "vae" phase (reference train.py:246-250: kf_weight = 0, every LGSSM parameter frozen): the chain runs
+    #                         forward only, without a tape, for the logged elbo_kf; nothing of it is differentiated
 
     def __init__(self, config):
         super().__init__()
@@ -87,11 +102,6 @@ class KVAE(nn.Module):
         # config noise values are variances
         self.kalman_filter = KalmanFilter(config.noise_transition ** 0.5, config.noise_emission ** 0.5,
                                           torch.zeros(self.z_dim), torch.eye(self.z_dim) * config.init_cov, dynamics)
-        # Optional second HIP stream for the LGSSM chain (set by kvae.train.train.Trainer): the chain is
-        # latency-bound (one wavefront per sequence, 256 of ~8000 wave slots) and independent of the decoder,
-        # so it overlaps with the decoder convolutions in forward AND backward (autograd replays each node
-        # on its forward stream).  compute_loss() joins the streams.
-        self.lgssm_stream = None
 
     # -- VAE halves -----------------------------------------------------------------------------
     def reparameterize(self, mu, var):
@@ -127,14 +137,18 @@ class KVAE(nn.Module):
         self.kalman_filter.dyn_params.reset_state()
         side = self.lgssm_stream if (self.training and a_samples.is_cuda) else None
         a_side = None
+        value_only = self.kf_value_only and self.training
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
-            a_lgssm = a_samples
-            if self.early_kf_backward and torch.is_grad_enabled() and a_samples.requires_grad:
+            a_lgssm = a_samples.detach() if value_only else a_samples
+            if self.early_kf_backward and not value_only and torch.is_grad_enabled() and a_samples.requires_grad:
                 a_side = a_lgssm = a_samples.detach().requires_grad_(True)
                 a_samples = _SideGradJoin.apply(a_samples, {"a_side": a_side, "side": side})
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), torch.set_grad_enabled(torch.is_grad_enabled() and not value_only):
                 smoothed = self.kalman_filter.smooth(a_lgssm, u, mask=mask)
+        elif value_only:
+            with torch.no_grad():
+                smoothed = self.kalman_filter.smooth(a_samples.detach(), u, mask=mask)
         else:
             smoothed = self.kalman_filter.smooth(a_samples, u, mask=mask)
         (mus_smooth, Sigmas_smooth, mus_filt, Sigmas_filt, mus_pred, Sigmas_pred, A_list, B_list, C_list) = smoothed
@@ -149,10 +163,14 @@ class KVAE(nn.Module):
             "state_probs": self.kalman_filter.dyn_params.state_seq,
         }
 
-    def compute_loss(self, x, outputs, kf_weight=1.0, vae_weight=1.0, mask=None, with_metrics=True):
+    def compute_loss(self, x, outputs, kf_weight=1.0, vae_weight=1.0, mask=None, with_metrics=True, weights_dev=None):
         """`with_metrics` (addition over the reference): True = the reference's behaviour (active-unit count and the
         two latent variances as Python numbers: three host syncs); "device" = the same statistics as device tensors
-        (`active_units`, `latent_variances`), no sync, capturable into a hipGraph; False = skip them."""
+        (`active_units`, `latent_variances`), no sync, capturable into a hipGraph; False = skip them.
+        `weights_dev` (addition): fp32 device tensor (vae_weight, kf_weight) that replaces the two floats - the kernels read it
+        at run time, so a step captured into a hipGraph follows the reference's phase weights (train.py:246-260)."""
+        if weights_dev is not None:
+            vae_weight, kf_weight = weights_dev[0], weights_dev[1]
         B, T = x.shape[:2]
         a, a_mu, a_var = outputs["a_samples"], outputs["a_mu"], outputs["a_var"]
         A_list, B_list, C_list = outputs["ABC"]
@@ -169,13 +187,24 @@ class KVAE(nn.Module):
             stats = ((variances > 1e-2).sum(), variances)
 
         def kf_elbo():
+            if self.kf_value_only and self.training:   # no tape, nothing to differentiate: the value for the log
+                with torch.no_grad():
+                    if side is None:
+                        return self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a.detach(), u, A_list,
+                                                       B_list, C_list, mask=mask)
+                    with torch.cuda.stream(side):
+                        v = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a.detach(), u, A_list,
+                                                    B_list, C_list, mask=mask)
+                    torch.cuda.current_stream().wait_stream(side)
+                    return v
             if a_side is not None:   # early_kf_backward: value and gradients of the LGSSM term on the side stream, now
                 with torch.cuda.stream(side):
                     v = self.kalman_filter.elbo(outputs["mus_smooth"], outputs["Sigmas_smooth"], a_side, u, A_list, B_list,
                                                 C_list, mask=mask)
                     done = torch.cuda.Event()
                     done.record(side)
-                    v.backward(torch.full_like(v, -float(kf_weight)))   # d loss / d elbo_kf
+                    # d loss / d elbo_kf = -kf_weight
+                    v.backward((-kf_weight).reshape(v.shape) if torch.is_tensor(kf_weight) else torch.full_like(v, -float(kf_weight)))
                 torch.cuda.current_stream().wait_event(done)   # the value only; _SideGradJoin waits for the gradients
                 return v.detach()
             if side is None:
@@ -187,10 +216,8 @@ class KVAE(nn.Module):
             torch.cuda.current_stream().wait_stream(side)   # join before the two ELBOs are combined
             return v
 
-        from kvae import _native
-        import os
-        head = os.environ.get("KVAE_LOSS_HEAD")
-        if head is None and a_side is not None:
+        head = _LOSS_HEAD
+        if head is None and (a_side is not None or (self.kf_value_only and self.training and side is not None)):
             head = "2"
         if ((head in ("1", "2") or (head is None and side is None)) and self.config.out_distr.lower() == "bernoulli"
                 and _native.fused_ok(x_mu) and x_mu.dtype == torch.float32
@@ -211,8 +238,9 @@ class KVAE(nn.Module):
                 z = getattr(self, "_zero_kf", None)
                 if z is None or z.device != x.device:
                     z = self._zero_kf = torch.zeros(1, device=x.device, dtype=torch.float32)
+                wd = weights_dev   # its kf_weight multiplies the zero standing in for the LGSSM term here
                 vae_loss_w, _, _, vae_elbo, recon, reg = LossHead.apply(
-                    lpx, regf, z, mk, self.beta, self.config.scale_reconstruction, vae_weight, 0.0)
+                    lpx, regf, z, mk, self.beta, self.config.scale_reconstruction, 0.0 if wd is not None else vae_weight, 0.0, wd)
                 elbo_kf = kf_elbo()
                 loss = vae_loss_w - kf_weight * elbo_kf
                 out = {"loss": loss, "elbo_total": -loss.detach(), "elbo_kf": elbo_kf, "elbo_vae_total": vae_elbo,
@@ -220,7 +248,8 @@ class KVAE(nn.Module):
             else:
                 elbo_kf = kf_elbo()
                 loss, elbo_total, elbo_kf_v, vae_elbo, recon, reg = LossHead.apply(
-                    lpx, regf, elbo_kf, mk, self.beta, self.config.scale_reconstruction, vae_weight, kf_weight)
+                    lpx, regf, elbo_kf, mk, self.beta, self.config.scale_reconstruction,
+                    0.0 if weights_dev is not None else vae_weight, 0.0 if weights_dev is not None else kf_weight, weights_dev)
                 out = {"loss": loss, "elbo_total": elbo_total, "elbo_kf": elbo_kf_v, "elbo_vae_total": vae_elbo,
                        "recon": recon, "kl": reg}
         else:
@@ -247,8 +276,7 @@ class KVAE(nn.Module):
         mask = mask.to(device=x.device, dtype=x.dtype)
         out = self.forward(x, u=u, mask=mask)
         _, _, C_list = out["ABC"]
-        a_imputed = (C_list @ out["mus_smooth"]).squeeze(-1)
-        a_filtered = (C_list @ out["mus_filt"]).squeeze(-1)
+        a_imputed, a_filtered = self.kalman_filter.emission_means(out["mus_smooth"], out["mus_filt"], C_list)
         dec = lambda a: self._to_pixels(self.decode_sequence(a))
         return {"x_recon": dec(out["a_samples"]), "x_imputed": dec(a_imputed), "x_filtered": dec(a_filtered),
                 "a_vae": out["a_samples"], "a_imputed": a_imputed, "a_filtered": a_filtered,

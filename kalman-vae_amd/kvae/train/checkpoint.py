@@ -15,10 +15,22 @@ class Checkpointer:
 
     @staticmethod
     def payload(model, optimizer, epoch, train_loss, val_loss):
+        """What the reference's Checkpointer writes (utils.py:190-198): plain-float hyperparameters and one state entry per
+        parameter that has been updated at least once.  The Trainer keeps lr (and with an LRScheduler `initial_lr`) in device
+        scalars and its Adam state in views of flat buffers with a zero-step entry for every parameter: tensor-valued
+        hyperparameters become floats, state tensors are copied out of the flat buffers, and entries that never saw a
+        gradient (frozen by the training phase in every step so far) are left out, as torch's Adam would have none."""
         opt_state = optimizer.state_dict()
-        for g in opt_state["param_groups"]:   # the Trainer keeps lr in a device scalar; the reference's files hold a float
-            if isinstance(g.get("lr"), torch.Tensor):
-                g["lr"] = float(g["lr"])
+        for g in opt_state["param_groups"]:
+            for k, v in list(g.items()):
+                if isinstance(v, torch.Tensor) and v.numel() == 1:
+                    g[k] = float(v)
+        state = {}
+        for idx, st in opt_state["state"].items():
+            if "step" in st and float(st["step"]) == 0.0:
+                continue
+            state[idx] = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+        opt_state["state"] = state
         return {"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": opt_state,
                 "train_loss": train_loss, "val_loss": val_loss}
 
@@ -41,9 +53,13 @@ def load_checkpoint(path, model, optimizer=None, map_location="cpu"):
     model.load_state_dict(payload["model_state"], strict=True)
     if optimizer is not None and "optimizer_state" in payload:
         lr_t = [g["lr"] for g in optimizer.param_groups]
+        # how THIS optimizer runs is not the file's business: a reference-written file says fused None / capturable False,
+        # which would turn a later capture of torch's Adam into a non-capturable one
+        keep = [{k: g[k] for k in ("fused", "capturable", "foreach", "differentiable") if k in g} for g in optimizer.param_groups]
         optimizer.load_state_dict(payload["optimizer_state"])
-        for g, t in zip(optimizer.param_groups, lr_t):   # keep the device scalar a captured step reads; refill it
-            if isinstance(t, torch.Tensor):
+        for g, t, kp in zip(optimizer.param_groups, lr_t, keep):
+            g.update(kp)
+            if isinstance(t, torch.Tensor):   # keep the device scalar a captured step reads; refill it
                 t.fill_(float(g["lr"]))
                 g["lr"] = t
         relink = getattr(optimizer, "_kvae_relink", None)   # a Trainer's optimizer: its state lives in flat buffers

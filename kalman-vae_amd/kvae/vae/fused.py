@@ -343,20 +343,21 @@ class LossHead(torch.autograd.Function):
     reference kvae/vae/losses.py:45-69, kvae/model/model.py:214-232).  Only `loss` carries gradient."""
 
     @staticmethod
-    def forward(ctx, lpx, regf, elbo_kf, mask, beta, scale, vae_w, kf_w):
+    def forward(ctx, lpx, regf, elbo_kf, mask, beta, scale, vae_w, kf_w, weights=None):
+        """weights: optional fp32 device tensor (vae_weight, kf_weight) read by the kernel at run time (overrides the floats)."""
         lpx, regf = lpx.contiguous(), regf.contiguous()
         mask = mask.contiguous() if mask is not None else None
         kf = elbo_kf.reshape(1).contiguous()
         b = beta.reshape(1).to(device=lpx.device, dtype=torch.float32).contiguous() if torch.is_tensor(beta) else \
             torch.full((1,), float(beta), device=lpx.device, dtype=torch.float32)
-        out, coef = torch.empty(6, device=lpx.device, dtype=torch.float32), torch.empty(2, device=lpx.device, dtype=torch.float32)
+        out, coef = torch.empty(6, device=lpx.device, dtype=torch.float32), torch.empty(3, device=lpx.device, dtype=torch.float32)
         lib = N.lib_for(lpx)
         lib.check(lib.dll.kvae_loss_head_fwd(N.ptr(lpx), N.ptr(regf), _optr(mask), N.ptr(kf), N.ptr(b), float(scale), float(vae_w),
-                                             float(kf_w), N.ptr(out), N.ptr(coef), lpx.numel(), N.stream_for(lpx)),
+                                             float(kf_w), _optr(weights), N.ptr(out), N.ptr(coef), lpx.numel(), N.stream_for(lpx)),
                   "kvae_loss_head_fwd")
         ctx.save_for_backward(coef, mask)
         ctx.set_materialize_grads(False)   # five of the six outputs never carry a gradient: no zero fills for them
-        ctx.kf_w, ctx.shape, ctx.kf_shape = float(kf_w), lpx.shape, elbo_kf.shape
+        ctx.shape, ctx.kf_shape = lpx.shape, elbo_kf.shape
         vals = out.unbind(0)
         ctx.mark_non_differentiable(*vals[1:])
         return vals
@@ -364,16 +365,16 @@ class LossHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_unused):
         if g_loss is None:
-            return (None,) * 8
+            return (None,) * 9
         coef, mask = ctx.saved_tensors
         g = g_loss.reshape(1).contiguous()
         g_lpx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
         g_reg = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
         g_kf = torch.empty(1, device=g.device, dtype=torch.float32)
         lib = N.lib_for(g)
-        lib.check(lib.dll.kvae_loss_head_bwd(N.ptr(g), N.ptr(coef), _optr(mask), ctx.kf_w, N.ptr(g_lpx), N.ptr(g_reg), N.ptr(g_kf),
+        lib.check(lib.dll.kvae_loss_head_bwd(N.ptr(g), N.ptr(coef), _optr(mask), N.ptr(g_lpx), N.ptr(g_reg), N.ptr(g_kf),
                                              g_lpx.numel(), N.stream_for(g)), "kvae_loss_head_bwd")
-        return g_lpx, g_reg, g_kf.reshape(ctx.kf_shape), None, None, None, None, None
+        return g_lpx, g_reg, g_kf.reshape(ctx.kf_shape), None, None, None, None, None, None
 
 
 class BernoulliFrameLogLik(torch.autograd.Function):

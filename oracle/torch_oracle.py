@@ -404,9 +404,20 @@ class OracleTrainer:
             self.sd[k].requires_grad_(True)
         self.opt = torch.optim.Adam([self.sd[k] for k in self.params], lr=lr, weight_decay=weight_decay)
 
-    def step(self, x, *, eps_a, eps_z, gumbel=None, mask=None):
+    def set_training_phase(self, phase):
+        """set_training_phase (train.py:142-207): "vae" trains encoder + decoder only; "warmup" also A, B, C (and Q of the
+        switching model); the alpha-network (lstm.*, head_w.*) / regime posterior stays frozen until "all"."""
+        assert phase in ("vae", "warmup", "all")
+        d = "kalman_filter.dyn_params."
+        for k in self.params:
+            vae = k.startswith("encoder.") or k.startswith("decoder.")
+            mats = k in (d + "A", d + "B", d + "C", d + "Q")
+            self.sd[k].requires_grad_(phase == "all" or vae or (phase == "warmup" and mats))
+
+    def step(self, x, *, eps_a, eps_z, gumbel=None, mask=None, **fw):
+        """fw: per-step overrides of the forward's keyword arguments (kf_weight of the current phase, train.py:246-260)."""
         self.opt.zero_grad(set_to_none=True)
-        out = kvae_forward(self.sd, x, mask, kind=self.kind, eps_a=eps_a, eps_z=eps_z, gumbel=gumbel, **self.fw)
+        out = kvae_forward(self.sd, x, mask, kind=self.kind, eps_a=eps_a, eps_z=eps_z, gumbel=gumbel, **{**self.fw, **fw})
         out["loss"].backward()
         gn = torch.nn.utils.clip_grad_norm_([self.sd[k] for k in self.params], self.clip)
         self.opt.step()

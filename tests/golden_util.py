@@ -28,6 +28,7 @@ LATENT_CASES = [
     ("latent_switch_K3_B4_T50", "switching"), ("latent_switch_K7_B2_T100", "switching"),
     ("masked_lstm_K3_B4_T20", "lstm"), ("masked_switch_K3_B4_T20", "switching"),
     ("masked_lstm_K3_B2_T16_grad", "lstm"), ("masked_switch_K3_B2_T16_grad", "switching"),
+    ("masked_lstm_K7_B2_T100", "lstm"), ("masked_switch_K7_B2_T100", "switching"),   # configs[3], non-degenerate (round 3)
     ("stress_lstm_z16_B2_T40_grad", "lstm"), ("stress_switch_z16_B2_T200", "switching"),
 ]
 SMOOTH_KEYS = ["mus_smooth", "Sigmas_smooth", "mus_filt", "Sigmas_filt", "mus_pred", "Sigmas_pred",

@@ -227,20 +227,25 @@ int kvae_colsum(const float *partials, float *out, int64_t rows, int64_t cols, v
   }
   return KVAE_OK;
 }
-int kvae_clip_adam(float *p, const float *g, float *m, float *v, int64_t n, const float *lr_dev, float lr, float *step_dev,
-                   float beta1, float beta2, float eps, float wd, float clip, const float *div_dev, float *norm_out, float *ws,
-                   void *) {
-  if (!p || !g || !m || !v || !step_dev || !ws) return KVAE_ERR_NULL;
-  if (n < 1) return KVAE_ERR_ARG;
+int kvae_clip_adam(float *p, const float *g, float *m, float *v, int64_t n, const int32_t *seg_of, int32_t n_seg,
+                   const float *seg_active, float *seg_steps, const float *lr_dev, float lr, float beta1, float beta2, float eps,
+                   float wd, float clip, const float *div_dev, float *norm_out, float *ws, void *) {
+  if (!p || !g || !m || !v || !seg_steps || !ws) return KVAE_ERR_NULL;
+  if (n < 1 || n_seg < 1 || n_seg > 1024 || (!seg_of && n_seg != 1)) return KVAE_ERR_ARG;
   const float inv = div_dev ? 1.0f / std::fmax(*div_dev, 1.0f) : 1.0f;
+  auto on = [&](int64_t i) { return !seg_active || seg_active[seg_of ? seg_of[i] : 0] != 0.f; };
   double ss = 0.0;
-  for (int64_t i = 0; i < n; ++i) ss += (double)(g[i] * inv) * (g[i] * inv);
+  for (int64_t i = 0; i < n; ++i)
+    if (on(i)) ss += (double)(g[i] * inv) * (g[i] * inv);
   const float total = (float)std::sqrt(ss);
   if (norm_out) *norm_out = total;
-  *step_dev += 1.0f;
+  for (int s = 0; s < n_seg; ++s)
+    if (!seg_active || seg_active[s] != 0.f) seg_steps[s] += 1.0f;
   const float scale = inv * (clip > 0.f ? std::fmin(clip / (total + 1e-6f), 1.0f) : 1.0f), lrv = lr_dev ? *lr_dev : lr;
-  const float bc1 = 1.0f - std::pow(beta1, *step_dev), bc2s = std::sqrt(1.0f - std::pow(beta2, *step_dev)), step_size = lrv / bc1;
   for (int64_t i = 0; i < n; ++i) {
+    if (!on(i)) continue;
+    const float step = seg_steps[seg_of ? seg_of[i] : 0];
+    const float bc1 = 1.0f - std::pow(beta1, step), bc2s = std::sqrt(1.0f - std::pow(beta2, step)), step_size = lrv / bc1;
     float gi = g[i] * scale;
     if (wd != 0.f) gi += wd * p[i];
     m[i] = m[i] + (gi - m[i]) * (1.0f - beta1);
@@ -705,7 +710,7 @@ int kvae_latent_reg_bwd(const float *a, const float *mu, const float *var, const
 // Scalar head of the objective: plain loops.
 extern "C" {
 int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, const float *elbo_kf, const float *beta,
-                       float scale, float vae_w, float kf_w, float *out, float *coef, int64_t n, void *) {
+                       float scale, float vae_w, float kf_w, const float *w_dev, float *out, float *coef, int64_t n, void *) {
   if (!lpx || !regf || !elbo_kf || !beta || !out || !coef) return KVAE_ERR_NULL;
   if (n < 1) return KVAE_ERR_ARG;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -713,14 +718,16 @@ int kvae_loss_head_fwd(const float *lpx, const float *regf, const float *mask, c
     const float mk = mask ? mask[i] : 1.f;
     s0 += lpx[i] * mk; s1 += regf[i] * mk; s2 += mk;
   }
+  if (w_dev) vae_w = w_dev[0], kf_w = w_dev[1];
   const float denom = s2 > 1.f ? s2 : 1.f, recon = s0 / denom, reg = s1 / denom;
   const float vae = scale * recon + beta[0] * reg, tot = vae_w * vae + kf_w * elbo_kf[0];
   out[0] = -tot; out[1] = tot; out[2] = elbo_kf[0]; out[3] = vae; out[4] = recon; out[5] = reg;
   coef[0] = -vae_w * scale / denom;
   coef[1] = -vae_w * beta[0] / denom;
+  coef[2] = kf_w;
   return KVAE_OK;
 }
-int kvae_loss_head_bwd(const float *g, const float *coef, const float *mask, float kf_w, float *g_lpx, float *g_regf, float *g_kf,
+int kvae_loss_head_bwd(const float *g, const float *coef, const float *mask, float *g_lpx, float *g_regf, float *g_kf,
                        int64_t n, void *) {
   if (!g || !coef || !g_lpx || !g_regf || !g_kf) return KVAE_ERR_NULL;
   if (n < 1) return KVAE_ERR_ARG;
@@ -729,7 +736,101 @@ int kvae_loss_head_bwd(const float *g, const float *coef, const float *mask, flo
     g_lpx[i] = g[0] * coef[0] * mk;
     g_regf[i] = g[0] * coef[1] * mk;
   }
-  g_kf[0] = -kf_w * g[0];
+  g_kf[0] = -coef[2] * g[0];
+  return KVAE_OK;
+}
+
+int kvae_lgssm_emission_means(const kvae_lgssm_problem *prob, const float *ms, const float *mf, float *a_s, float *a_f, void *) {
+  if (!prob || !prob->C.ptr || (!ms != !a_s) || (!mf != !a_f) || (!a_s && !a_f)) return KVAE_ERR_NULL;
+  if (prob->B < 1 || prob->T < 1 || prob->n < 1 || prob->p < 1 || prob->n > KVAE_MAX_DIM || prob->p > KVAE_MAX_DIM) return KVAE_ERR_DIMS;
+  const int n = prob->n, p = prob->p;
+  for (int64_t b = 0; b < prob->B; ++b)
+    for (int64_t t = 0; t < prob->T; ++t)
+      for (int i = 0; i < p; ++i) {
+        const float *c = prob->C.ptr + b * prob->C.sb + t * prob->C.st + (int64_t)i * n;
+        const int64_t q = b * prob->T + t;
+        float s = 0.f, f = 0.f;
+        for (int k = 0; k < n; ++k) {
+          if (ms) s = std::fma(c[k], ms[q * n + k], s);
+          if (mf) f = std::fma(c[k], mf[q * n + k], f);
+        }
+        if (a_s) a_s[q * p + i] = s;
+        if (a_f) a_f[q * p + i] = f;
+      }
+  return KVAE_OK;
+}
+
+// ---- alpha-network parameter gradients and linear heads: plain-loop twins of rnn_wgrad.h / small_linear.h --------------
+int64_t kvae_rnn_wgrad_ws_floats(const kvae_wgrad_problem *, int32_t) { return 1; }
+int kvae_rnn_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, void *) {
+  if (!probs || !ws) return KVAE_ERR_NULL;
+  if (n < 1 || n > 4) return KVAE_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const kvae_wgrad_problem &p = probs[i];
+    const int C = p.H + p.I + (p.bias ? 1 : 0);
+    if (!p.d || (p.H > 0 && !p.h) || (p.I > 0 && !p.x)) return KVAE_ERR_NULL;
+    if (p.N < 1 || p.R < 1 || p.R > 256 || p.H < 0 || p.I < 0 || C < 1 || C > 256 || p.T < 1 || p.shift < -1 || p.shift > 1 ||
+        p.N % p.T != 0)
+      return KVAE_ERR_ARG;
+    for (int r = 0; r < p.R; ++r)
+      for (int c = 0; c < C; ++c) {
+        double s = 0.0;
+        for (int64_t q = 0; q < p.N; ++q) {
+          float xv;
+          if (c < p.H) {
+            const int t = (int)(q % p.T) + p.shift;
+            xv = (t >= 0 && t < p.T) ? p.h[(q + p.shift) * p.h_stride + c] : 0.f;
+          } else if (c < p.H + p.I) {
+            xv = p.x[q * p.x_stride + (c - p.H)];
+          } else {
+            xv = 1.f;
+          }
+          s += (double)p.d[q * p.d_stride + r] * xv;
+        }
+        if (c < p.H) { if (p.g_wh) p.g_wh[(int64_t)r * p.H + c] = (float)s; }
+        else if (c < p.H + p.I) { if (p.g_wx) p.g_wx[(int64_t)r * p.I + (c - p.H)] = (float)s; }
+        else if (p.g_b) p.g_b[r] = (float)s;
+      }
+  }
+  return KVAE_OK;
+}
+int kvae_linear_fwd(const float *x, int64_t xs, int64_t N, int32_t F, const float *W, const float *b, int32_t O, int32_t softmax,
+                    float *y, void *) {
+  if (!x || !W || !y) return KVAE_ERR_NULL;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (softmax && O > 16)) return KVAE_ERR_DIMS;
+  for (int64_t n = 0; n < N; ++n) {
+    float mx = -INFINITY;
+    for (int o = 0; o < O; ++o) {
+      float acc = b ? b[o] : 0.f;
+      for (int f = 0; f < F; ++f) acc = std::fma(x[n * xs + f], W[o * F + f], acc);
+      y[n * O + o] = acc;
+      mx = std::fmax(mx, acc);
+    }
+    if (softmax) {
+      float sum = 0.f;
+      for (int o = 0; o < O; ++o) sum += (y[n * O + o] = std::exp(y[n * O + o] - mx));
+      for (int o = 0; o < O; ++o) y[n * O + o] /= sum;
+    }
+  }
+  return KVAE_OK;
+}
+int kvae_linear_bwd_input(const float *g, const float *y, int64_t N, int32_t F, const float *W, int32_t O, float *g_logit, float *dx,
+                          int64_t dxs, void *) {
+  if (!g || !W || !dx || (y && !g_logit)) return KVAE_ERR_NULL;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (y && O > 16)) return KVAE_ERR_DIMS;
+  for (int64_t n = 0; n < N; ++n) {
+    float gl[256], dot = 0.f;
+    for (int o = 0; o < O && y; ++o) dot = std::fma(g[n * O + o], y[n * O + o], dot);
+    for (int o = 0; o < O; ++o) {
+      gl[o] = y ? y[n * O + o] * (g[n * O + o] - dot) : g[n * O + o];
+      if (y) g_logit[n * O + o] = gl[o];
+    }
+    for (int f = 0; f < F; ++f) {
+      float acc = 0.f;
+      for (int o = 0; o < O; ++o) acc = std::fma(gl[o], W[o * F + f], acc);
+      dx[n * dxs + f] = acc;
+    }
+  }
   return KVAE_OK;
 }
 }

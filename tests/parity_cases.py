@@ -499,6 +499,15 @@ def vae_heads_vs_torch(DEV, N):
             assert rel_err(got.detach().cpu(), want.detach()) < 2e-5
         for got, want in zip(dev_in, ref_in):
             assert rel_err(got.grad.cpu(), want.grad) < 2e-5
+        # the same through DEVICE scalars for (vae_weight, kf_weight): the by-value floats are then ignored
+        dev_w = [t.clone().to(DEV).requires_grad_(True) for t in (lpx, rg, kf)]
+        out_w = LossHead.apply(dev_w[0], dev_w[1], dev_w[2], None if mk is None else mk.to(DEV), torch.tensor(0.7).to(DEV), 0.3, 0.0, 0.0,
+                               torch.tensor([1.5, 0.8]).to(DEV))
+        (out_w[0] * 2.0).backward()
+        for got, want in zip(out_w, out):
+            assert torch.equal(got.detach().cpu(), want.detach().cpu())
+        for got, want in zip(dev_w, dev_in):
+            assert torch.equal(got.grad.cpu(), want.grad.cpu())
 
 
 def colsum_pair_vs_torch(DEV):
@@ -529,3 +538,106 @@ def dec_up_workgroup_cap(DEV):
         assert lib.dll.kvae_dec_up_partial_rows(12800, 8) == 256
     finally:
         lib.dll.kvae_dec_up_set_workgroups(0 if default == 256 else default)
+
+
+def check_phases(g, set_phase, run_step, params_now, adam_steps, value_tol=1e-4, param_tol=1e-3):
+    """One implementation of the training step against the reference's three phases as recorded in phases_*.npz
+    (tests/golden/make_goldens_r3.py: the reference's own set_training_phase and train_one_epoch, two steps per phase in the
+    order vae -> warmup -> all, ONE Adam over all parameters).
+      set_phase(phase); run_step(phase, i, kf_weight) -> dict(loss, elbo_kf, elbo_vae_total); params_now() -> {name: tensor};
+      adam_steps() -> per-parameter step counts in .parameters() order."""
+    buffers = ("kalman_filter.Q", "kalman_filter.R", "kalman_filter.I", "kalman_filter.mu0", "kalman_filter.Sigma0")
+    names = [k[3:] for k in g if k.startswith("sd.") and k[3:] not in buffers]   # .parameters() order (the generator asserts it)
+    prev = {k: v.clone() for k, v in params_now().items()}
+    for phase in ("vae", "warmup", "all"):
+        set_phase(phase)
+        kf_w = float(g[f"{phase}.kf_weight"])
+        outs = [run_step(phase, i, kf_w) for i in range(2)]
+        for k in ("loss", "elbo_kf", "elbo_vae_total"):
+            mean = sum(float(o[k]) for o in outs) / 2
+            want = float(g[f"{phase}.mean_{k}"])
+            assert abs(mean - want) <= value_tol * abs(want), (phase, k, mean, want)
+        now = {k: v.clone() for k, v in params_now().items()}
+        for i, k in enumerate(names):
+            unchanged = bool(g[f"{phase}.unchanged"][i])
+            if unchanged:   # frozen by the phase (or a zero gradient on zero moments): bit-identical, as in the reference
+                assert torch.equal(now[k].cpu(), prev[k].cpu()), (phase, k, "moved but the reference left it bit-identical")
+            else:
+                assert not torch.equal(now[k].cpu(), prev[k].cpu()), (phase, k, "did not move")
+                dn, want = float((now[k].cpu() - prev[k].cpu()).norm()), float(g[f"{phase}.delta_norm.{k}"])
+                # Adam's normalised update: every entry moves by ~lr whatever its gradient, so the norm of the change is tight
+                assert abs(dn - want) <= 2e-2 * want + 1e-7, (phase, k, dn, want)
+            if f"{phase}.after.{k}" in g:
+                # entries whose gradient is O(1e-8) are rounding-sensitive under Adam (lr*g/(|g|+eps)): 1e-3 of max|param|
+                assert rel_err(now[k].cpu(), g[f"{phase}.after.{k}"]) < param_tol, (phase, k)
+        prev = now
+    assert [float(s) for s in adam_steps()] == [float(s) for s in g["adam_steps"]]
+
+
+def rnn_wgrad_vs_torch(DEV):
+    """kvae_rnn_wgrad (dW_hh | dW_ih | db of a recurrence, dW | db of a head; f32 matrix cores, split over the rows, fixed-order
+    second stage) against the products torch would form: LSTM-shaped (200 x [50 | 2 | 1], h_{t-1}), both GRU directions in one
+    batched call (h_{t-1} / h_{t+1} on the two halves of a [.., 2H] sequence), a head (K x [H | 1]), ragged row counts."""
+    from kvae.kalman.lgssm_ops import rnn_wgrad
+    g = torch.Generator().manual_seed(17)
+    for Bsz, T, H, I, R in [(3, 7, 50, 2, 200), (256, 50, 50, 2, 200), (5, 1, 50, 2, 200), (2, 9, 13, 3, 37)]:
+        d = torch.randn(Bsz * T, R, generator=g)
+        h = torch.randn(Bsz, T, H, generator=g)
+        x = torch.randn(Bsz * T, I, generator=g)
+        hp = torch.cat([torch.zeros(Bsz, 1, H), h[:, :-1]], 1).reshape(Bsz * T, H)
+        (gwh, gwx, gb), = rnn_wgrad(d.to(DEV), [dict(d=d.to(DEV), h=h.reshape(Bsz * T, H).to(DEV), shift=-1, T=T, x=x.to(DEV))])
+        dd = d.double()
+        for got, want in ((gwh, dd.t() @ hp.double()), (gwx, dd.t() @ x.double()), (gb, dd.sum(0))):
+            assert rel_err(got.cpu(), want.float()) < 2e-5
+    Bsz, T, H, I = 4, 11, 50, 2
+    h2 = torch.randn(Bsz, T, 2 * H, generator=g)
+    x = torch.randn(Bsz * T, I, generator=g)
+    dpi, dph = torch.randn(2, Bsz * T, 3 * H, generator=g), torch.randn(2, Bsz * T, 3 * H, generator=g)
+    zero = torch.zeros(Bsz, 1, H)
+    hp = (torch.cat([zero, h2[:, :-1, :H]], 1), torch.cat([h2[:, 1:, H:], zero], 1))
+    h2d = h2.reshape(Bsz * T, 2 * H).to(DEV)
+    probs = []
+    for dr in (0, 1):
+        probs.append(dict(d=dpi[dr].to(DEV), x=x.to(DEV)))
+        probs.append(dict(d=dph[dr].to(DEV), h=h2d[:, dr * H:(dr + 1) * H], shift=-1 if dr == 0 else 1, T=T))
+    res = rnn_wgrad(h2d, probs)
+    for dr in (0, 1):
+        (_, gwx, gbi), (gwh, _, gbh) = res[2 * dr], res[2 * dr + 1]
+        assert rel_err(gwx.cpu(), (dpi[dr].double().t() @ x.double()).float()) < 2e-5
+        assert rel_err(gwh.cpu(), (dph[dr].double().t() @ hp[dr].reshape(Bsz * T, H).double()).float()) < 2e-5
+        assert rel_err(gbi.cpu(), dpi[dr].double().sum(0).float()) < 2e-5 and rel_err(gbh.cpu(), dph[dr].double().sum(0).float()) < 2e-5
+    run1 = rnn_wgrad(h2d, probs)   # fixed summation order: bit-identical from run to run
+    assert all(torch.equal(a, b) for r0, r1 in zip(res, run1) for a, b in zip(r0, r1) if a is not None)
+
+
+def small_linear_vs_torch(DEV):
+    """SmallLinear (+ fused softmax) forward, input gradient and parameter gradients against torch.nn.functional.linear /
+    softmax autograd: the alpha head (K x 50, softmax), the regime posterior's heads (K^2 x 100 on [B,T,100], K x 100 on the
+    strided rows h_seq[:, 0])."""
+    from kvae.kalman.lgssm_ops import SmallLinear, small_linear_supported
+    g = torch.Generator().manual_seed(23)
+    for lead, F, O, softmax, strided in [((6, 9), 50, 3, True, False), ((256, 50), 50, 7, True, False), ((5, 8), 100, 9, False, False),
+                                         ((3, 4), 100, 49, False, False), ((7,), 100, 7, False, True), ((2, 3), 17, 5, False, False)]:
+        if strided:   # rows T*F apart, as h_seq[:, 0]
+            base = torch.randn(lead[0], 6, F, generator=g)
+            x_ref = base[:, 0].clone().requires_grad_(True)
+            base_dev = base.to(DEV).requires_grad_(True)
+            x_dev = base_dev[:, 0]
+        else:
+            x0 = torch.randn(*lead, F, generator=g)
+            x_ref, x_dev = x0.clone().requires_grad_(True), x0.to(DEV).requires_grad_(True)
+        w0, b0 = torch.randn(O, F, generator=g) * 0.3, torch.randn(O, generator=g)
+        up = torch.randn(*lead, O, generator=g)
+        w_ref, b_ref = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y_ref = torch.nn.functional.linear(x_ref, w_ref, b_ref)
+        if softmax:
+            y_ref = torch.softmax(y_ref, -1)
+        (y_ref * up).sum().backward()
+        w_dev, b_dev = w0.to(DEV).requires_grad_(True), b0.to(DEV).requires_grad_(True)
+        assert small_linear_supported(x_dev, w_dev, softmax)
+        y = SmallLinear.apply(x_dev, w_dev, b_dev, softmax)
+        (y * up.to(DEV)).sum().backward()
+        assert rel_err(y.detach().cpu(), y_ref.detach()) < 1e-5
+        gx = base_dev.grad[:, 0] if strided else x_dev.grad
+        assert rel_err(gx.cpu(), x_ref.grad) < 2e-5
+        assert rel_err(w_dev.grad.cpu(), w_ref.grad) < 2e-5 and rel_err(b_dev.grad.cpu(), b_ref.grad) < 2e-5

@@ -122,3 +122,12 @@ def test_reference_written_checkpoint_loads(kind, tmp_path):
     assert list(raw["model_state"]) == list(model.state_dict())        # same keys, same order
     ours = Checkpointer.payload(model, opt, 1, meta["train_loss"], meta["val_loss"])
     assert set(ours) == set(raw) and set(ours["optimizer_state"]) == set(raw["optimizer_state"])
+    # ... down to the types of every hyperparameter, also with an LRScheduler attached (torch stores `initial_lr` as a clone
+    # of a tensor lr) and a tensor learning rate (what the Trainer's optimizer holds)
+    opt2 = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-3), weight_decay=0.0)
+    torch.optim.lr_scheduler.ExponentialLR(opt2, gamma=0.9)
+    ours2 = Checkpointer.payload(model, opt2, 1, 0.0, 0.0)["optimizer_state"]["param_groups"][0]
+    theirs = raw["optimizer_state"]["param_groups"][0]
+    assert type(ours2["initial_lr"]) is float and type(ours2["lr"]) is float
+    for k, v in theirs.items():
+        assert type(ours2[k]) is type(v), (k, type(ours2[k]), type(v))

@@ -296,6 +296,15 @@ def test_enc_mid_gpu(N, side):
     parity_cases.enc_mid_vs_torch(DEV, N, side)
 
 
+def test_rnn_wgrad_gpu():
+    """No library GEMM on the path: LSTM / bi-GRU / head parameter gradients on the f32 matrix cores vs torch products."""
+    parity_cases.rnn_wgrad_vs_torch(DEV)
+
+
+def test_small_linear_gpu():
+    parity_cases.small_linear_vs_torch(DEV)
+
+
 @pytest.mark.parametrize("shape", [(256, 50, 1, 32, 32), (2, 3, 1, 32, 32), (1, 2, 3, 5, 7)])
 def test_bce_frames_gpu(shape):
     parity_cases.bce_frames_vs_torch(DEV, *shape)

@@ -63,6 +63,9 @@ def check_latent(kf, g, a, outs, elbo, name, tol_scale=1.0):
             assert rel_err(v.cpu()[:, ::8], g[k + "_every8"]) < tol, k
     assert rel_err(kf.dyn_params.state_seq.cpu(), g["state_seq"]) < tol
     assert rel_err(elbo.cpu(), g["elbo"]) < max(tol, 2e-5), "elbo"
+    if "a_imputed" in g:   # what KVAE.impute decodes (model.py:279-288): C_t mu_t|T and C_t mu_t|t, fused read-out
+        a_imp, a_fil = kf.emission_means(outs[0], outs[2], outs[8])
+        assert rel_err(a_imp.cpu(), g["a_imputed"]) < 1e-4 and rel_err(a_fil.cpu(), g["a_filtered"]) < 1e-4
     if "grad.a" not in g:
         return
     params = dict(kf.dyn_params.named_parameters())
@@ -244,7 +247,7 @@ def test_clip_adam_c_abi_vs_torch(hostsim_backend, clip, wd, div):
     ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([ref], lr=3e-3, weight_decay=wd)
     p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
-    step, norm, ws = torch.zeros(()), torch.zeros(()), torch.empty(1024)
+    step, norm, ws = torch.zeros(1), torch.zeros(()), torch.empty(1024)
     cnt = torch.tensor([div]) if div else None
     for it in range(3):
         grad = torch.randn(n, generator=g) * (it + 1)
@@ -252,11 +255,54 @@ def test_clip_adam_c_abi_vs_torch(hostsim_backend, clip, wd, div):
         ref.grad = gref.clone()
         total = torch.nn.utils.clip_grad_norm_([ref], clip) if clip > 0 else gref.norm()
         opt.step()
-        rc = hostsim_backend.dll.kvae_clip_adam(N.ptr(p), N.ptr(grad), N.ptr(m), N.ptr(v), n, None, 3e-3, N.ptr(step), 0.9, 0.999, 1e-8,
-                                               wd, clip, N.ptr(cnt) if cnt is not None else None, N.ptr(norm), N.ptr(ws), None)
+        rc = hostsim_backend.dll.kvae_clip_adam(N.ptr(p), N.ptr(grad), N.ptr(m), N.ptr(v), n, None, 1, None, N.ptr(step), None, 3e-3,
+                                               0.9, 0.999, 1e-8, wd, clip, N.ptr(cnt) if cnt is not None else None, N.ptr(norm),
+                                               N.ptr(ws), None)
         assert rc == 0
         assert abs(float(norm) - float(total)) <= 1e-5 * float(total)
     assert float(step) == 3.0
     assert float((p - ref.detach()).abs().max()) < 2e-6
     st = opt.state[ref]
     assert rel_err(m, st["exp_avg"]) < 1e-5 and rel_err(v, st["exp_avg_sq"]) < 5e-5   # (v squares the clip scale: twice its rounding)
+
+
+def test_clip_adam_frozen_segments_vs_torch(hostsim_backend):
+    """Three parameter tensors in one flat buffer, the middle one frozen for the first two of four steps (requires_grad False: the
+    reference's training phases, train.py:142-207) - clip_grad_norm_ + torch.optim.Adam skip a parameter whose grad is None (no
+    norm contribution, no moment / step / value update, bias correction from ITS OWN step count once it thaws), and so must the
+    segment mask of kvae_clip_adam."""
+    from kvae import _native as N
+    g = torch.Generator().manual_seed(8)
+    sizes = [7, 300, 41]
+    refs = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in sizes]
+    opt = torch.optim.Adam(refs, lr=2e-3)
+    n = sum(sizes)
+    p = torch.cat([r.detach().clone() for r in refs])
+    m, v = torch.zeros(n), torch.zeros(n)
+    seg_of = torch.repeat_interleave(torch.arange(3, dtype=torch.int32), torch.tensor(sizes))
+    steps, norm, ws = torch.zeros(3), torch.zeros(()), torch.empty(1024)
+    for it in range(4):
+        frozen = it < 2
+        active = torch.tensor([1.0, 0.0 if frozen else 1.0, 1.0])
+        grads = [torch.randn(s, generator=g) * 3 for s in sizes]
+        for r, gr, a in zip(refs, grads, active):
+            r.grad = gr.clone() if a else None
+        total = torch.nn.utils.clip_grad_norm_(refs, 1.5)
+        opt.step()
+        flat_g = torch.cat(grads)   # the frozen slot holds garbage on purpose: the mask, not a zero gradient, must exclude it
+        rc = hostsim_backend.dll.kvae_clip_adam(N.ptr(p), N.ptr(flat_g), N.ptr(m), N.ptr(v), n, N.ptr(seg_of), 3, N.ptr(active),
+                                               N.ptr(steps), None, 2e-3, 0.9, 0.999, 1e-8, 0.0, 1.5, None, N.ptr(norm), N.ptr(ws), None)
+        assert rc == 0
+        assert abs(float(norm) - float(total)) <= 1e-5 * float(total)
+        if frozen:
+            assert torch.equal(p[7:307], refs[1].detach()) and float(m[7:307].abs().max()) == 0.0   # bit-identical, no state
+    assert steps.tolist() == [4.0, 2.0, 4.0]
+    assert float((p - torch.cat([r.detach() for r in refs])).abs().max()) < 2e-6
+    assert [float(opt.state[r]["step"]) for r in refs] == [4.0, 2.0, 4.0]
+    assert rel_err(m, torch.cat([opt.state[r]["exp_avg"] for r in refs])) < 1e-5
+
+
+def test_rnn_wgrad_and_small_linear_hostsim(hostsim_backend):
+    import parity_cases
+    parity_cases.rnn_wgrad_vs_torch("cpu")
+    parity_cases.small_linear_vs_torch("cpu")

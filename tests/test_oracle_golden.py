@@ -97,6 +97,26 @@ def test_train_step(name, kind):
             assert rel_err(tr.sd[k].detach(), g["after." + k]) < 1e-3, k
 
 
+@pytest.mark.parametrize("name,kind", [("phases_lstm_K3", "lstm"), ("phases_switch_K3", "switching")])
+def test_training_phases(name, kind):
+    """The oracle's phases against the reference's own set_training_phase + train_one_epoch (two steps per phase, one Adam
+    over all parameters; tests/golden/make_goldens_r3.py): epoch means, who moved, the parameters after each phase and Adam's
+    per-parameter step counts."""
+    import parity_cases
+    g = load(name)
+    tr = O.OracleTrainer(sub(g, "sd."), kind, lr=float(g["lr"]), clip=float(g["clip"]), beta=float(g["beta"]))
+
+    def run_step(phase, i, kf_weight):
+        x = g[f"frames{i}"].float()
+        out = tr.step(x, eps_a=g[f"{phase}.eps_a{i}"], eps_z=g[f"{phase}.eps_z{i}"], gumbel=g.get(f"{phase}.gumbel{i}"),
+                      mask=torch.ones(x.shape[:2]), kf_weight=kf_weight)
+        return {k: out[k].detach() for k in ("loss", "elbo_kf", "elbo_vae_total")}
+
+    parity_cases.check_phases(g, tr.set_training_phase, run_step, lambda: {k: tr.sd[k].detach() for k in tr.params},
+                              lambda: [float(tr.opt.state[tr.sd[k]]["step"]) if tr.opt.state.get(tr.sd[k]) else 0.0
+                                       for k in tr.params], value_tol=1e-5)
+
+
 # ---- the C restatement (oracle/lgssm_oracle.c) against the same goldens ---------------------------
 @pytest.mark.parametrize("name,kind", [c for c in LATENT_CASES if "K3_B4_T50" in c[0] or "z16" in c[0]
                                        or "masked_switch" in c[0] or "T12_u" in c[0]])
