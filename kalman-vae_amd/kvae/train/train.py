@@ -23,6 +23,7 @@ losses.py:82), so the global-batch gradient is sum_r(count_r * grad_r) / sum_r(c
 gradient by its own count, the count rides in one extra slot of the same buffer, and ONE sum-all-reduce carries both
 (SURVEY.md section 5).  With mask == 1 and equal shards this is the plain mean.
 """
+import gc
 import os
 import weakref
 from contextlib import contextmanager
@@ -124,7 +125,10 @@ class Trainer:
             if prev is not None and prev is not self:
                 prev._release()   # its captured graphs would keep updating storage the parameters no longer live in
             self._flatten_optimizer(n_par, dev)
-            self.opt._kvae_relink = self.relink_optimizer_state
+            # (a weak method: the optimizer must not keep its Trainer - and the Trainer's captured graphs - alive in a reference
+            # cycle that only the cyclic collector frees, possibly in the middle of a later capture)
+            relink = weakref.WeakMethod(self.relink_optimizer_state)
+            self.opt._kvae_relink = lambda: relink() and relink()()
             model._flat_trainer = weakref.ref(self)
         self._released = False
         dyn = model.kalman_filter.dyn_params
@@ -427,9 +431,16 @@ class Trainer:
         from .. import _native
         lib = _native.lib_for(x)
         prev = lib.dll.kvae_dec_up_set_workgroups(self._decoder_workgroups(x.shape[0]))
+        # An object the cyclic collector happens to free DURING capture (an older Trainer's hipGraph, a tensor of its pool) makes
+        # HIP calls that are illegal while a stream captures, and the process aborts: collect now, and not again until done.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             return self._capture_graphs(x, mask)
         finally:   # process-wide setting: only the launches recorded above are meant
+            if gc_was_on:
+                gc.enable()
             lib.dll.kvae_dec_up_set_workgroups(prev if prev != 256 else 0)
 
     def _capture_graphs(self, x, mask=None):

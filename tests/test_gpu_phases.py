@@ -58,9 +58,12 @@ def test_trainer_reproduces_the_recorded_reference_step(name, kind, use_graph):
     assert rel_err(out["elbo_vae_total"].cpu(), g["elbo_vae"]) < 1e-4
     assert rel_err(out["grad_norm"].cpu(), g["grad_norm"]) < 1e-3
     names = [k for k, _ in model.named_parameters()]
+    # the fixture holds the gradients AFTER clip_grad_norm_ scaled them in place; the flat buffer is left unscaled (kvae_clip_adam
+    # applies the factor on the fly)
+    scale = min(1.0, float(g["clip"]) / (float(out["grad_norm"]) + 1e-6))
     for k, gv in zip(names, tr.grad_views):
         ref = float(g["gradnorm." + k])
-        assert abs(float(gv.norm()) - ref) <= 2e-3 * ref + 1e-6, k
+        assert abs(float(gv.norm()) * scale - ref) <= 2e-3 * ref + 1e-6, k
     sd = model.state_dict()
     checked = 0
     for k in names:

@@ -245,7 +245,7 @@ def test_early_lgssm_backward_gives_the_same_step(kind, monkeypatch):
         monkeypatch.setenv("KVAE_EARLY_KF_BWD", "1" if early else "0")
         model = _model(kind, seed=6)
         tr = Trainer(model, lr=3e-3, grad_clip_norm=10.0, use_graph=True)
-        assert model.lgssm_stream is not None and model.early_kf_backward is early
+        assert tr.lgssm_stream is not None and tr.early_kf_backward is early and model.lgssm_stream is None   # the schedule lives in the trainer
         with noise.inject(**nz):
             out = tr.step(x, mask)
             loss1, kf1, grad1 = float(out["loss"]), float(out["elbo_kf"]), tr.flat_grad.detach().clone().cpu()
