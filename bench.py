@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — sequences/sec of one ELBO training step of the KVAE on synthetic 32x32xT bouncing-ball video.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c4-lstm|c5|c5-lstm]
 
 Workloads (per GPU; weak scaling):
   c2 (default)  BASELINE.json configs[1] / configs[2]: dynamics 'lstm', K=3 modes, z=4, a=2, B=256 sequences of T=50
-  c5            BASELINE.json configs[4] shard: z = u = 16, T = 200, B = 512 per GPU (4096 over 8 GPUs)
+  c4 / c4-lstm  BASELINE.json configs[3]: K=7, T=100, B=32 (the reference's batch), switching / lstm dynamics; also times the
+                eval-mode imputation (`KVAE.impute` with the block mask) the config names
+  c5 / c5-lstm  BASELINE.json configs[4] shard: z = u = 16, T = 200, B = 512 per GPU (4096 over 8 GPUs); c5 is the switching
+                model (per-step Q: the 21 804 B/step SURVEY 8(d) quotes), c5-lstm the shared-Q variant
 Any of --batch / --seq-len / --z-dim / --dynamics / --modes overrides the preset; `config.workload` always names what ran.
+The default invocation (no workload flag) times c2 as the headline and then appends short runs of c4, c4-lstm and c5 as
+`"also": {...}` (ms/step, sequences/s, roofline of their dominant LGSSM kernel; c4 with impute and its CPU baseline), so
+that one driver-timed line witnesses every BASELINE config that fits one GPU (`--also none` skips them).
 
 A step = zero_grad + forward (incl. sigmoid(x_logits)) + loss (incl. the active-unit statistics of the reference's
 compute_loss, kept on the device) + backward + [one flat RCCL all-reduce] + clip_grad_norm_(10) + Adam (reference
@@ -40,12 +46,20 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); meas
 
 PRESETS = {
     "c2": dict(batch=256, seq_len=50, z_dim=4, dynamics="lstm", modes=3),
-    "c5": dict(batch=512, seq_len=200, z_dim=16, dynamics="lstm", modes=3),
+    "c4": dict(batch=32, seq_len=100, z_dim=4, dynamics="switching", modes=7, impute=True),
+    "c4-lstm": dict(batch=32, seq_len=100, z_dim=4, dynamics="lstm", modes=7, impute=True),
+    "c5": dict(batch=512, seq_len=200, z_dim=16, dynamics="switching", modes=3),
+    "c5-lstm": dict(batch=512, seq_len=200, z_dim=16, dynamics="lstm", modes=3),
 }
+ALSO_DEFAULT = ("c4", "c4-lstm", "c5")          # appended to the default run (python bench.py), each a few seconds
+ALSO_STEPS = {"c4": 100, "c4-lstm": 100, "c5": 20}
 BASELINE_NAMES = {
     (256, 50, 4, "lstm", 3): "BASELINE configs[1] (configs[2] per-GPU shard)",
-    (512, 200, 16, "lstm", 3): "BASELINE configs[4] per-GPU shard (z=u=16, T=200, 512 of 4096 sequences)",
-    (512, 200, 16, "switching", 3): "BASELINE configs[4] per-GPU shard, switching dynamics (per-step Q)",
+    (32, 100, 4, "switching", 7): "BASELINE configs[3] (switching-LDS, K=7, T=100; the reference's own batch of 32)",
+    (32, 100, 4, "lstm", 7): "BASELINE configs[3] with the LSTM alpha-net (K=7, T=100, batch of 32)",
+    (512, 200, 16, "lstm", 3): "BASELINE configs[4] per-GPU shard with the LSTM alpha-net (shared Q)",
+    (512, 200, 16, "switching", 3): "BASELINE configs[4] per-GPU shard (z=u=16, T=200, 512 of 4096 sequences), switching "
+                                    "dynamics: the per-step-Q variant SURVEY 8(d) quotes 21 804 B/step for",
 }
 
 
@@ -72,11 +86,32 @@ def parse_args(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="keep the LGSSM chain on the main stream")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher/rendezvous rehearsal on the CPU (gloo): no model, no GPU, marks the line dry_run")
+    ap.add_argument("--also", default=None,
+                    help="comma-separated presets measured briefly after the headline and appended as `also` "
+                         "('none' to skip; default: c4,c4-lstm,c5 on one GPU when no other workload flag is given)")
+    ap.add_argument("--impute", action="store_true", help="also time eval-mode KVAE.impute (default for the c4 presets)")
+    ap.add_argument("--graph-allreduce", action="store_true", help="N > 1: capture the RCCL all-reduce into the step graph")
     args = ap.parse_args(argv)
-    for k, v in PRESETS[args.config].items():
-        if getattr(args, k) is None:
-            setattr(args, k, v)
+    plain = args.config == "c2" and all(getattr(args, k) is None for k in ("batch", "seq_len", "dynamics", "modes", "z_dim")) \
+        and not (args.no_graph or args.no_roofline or args.no_steady or args.no_overlap) and args.gpus == 1
+    if args.also is None:
+        args.also = list(ALSO_DEFAULT) if plain else []
+    else:
+        args.also = [] if args.also.lower() in ("", "none") else [a for a in args.also.split(",") if a]
+    for a in args.also:
+        if a not in PRESETS:
+            ap.error(f"--also: unknown preset {a}")
+    args.cpu_in_also = False
+    apply_preset(args)
     return args
+
+
+def apply_preset(args):
+    for k, v in PRESETS[args.config].items():
+        if k == "impute":
+            args.impute = bool(args.impute or v)
+        elif getattr(args, k) is None:
+            setattr(args, k, v)
 
 
 def workload_name(args, cfg_dims):
@@ -99,9 +134,27 @@ def _free_port():
     return port
 
 
+def visible_gpus():
+    """GPUs this process could open, counted WITHOUT touching the HIP runtime (the launcher parent must stay free of it: on
+    ROCm torch.cuda.device_count() calls hipGetDeviceCount, which brings HSA up in a process that only spawns ranks): KFD's
+    topology in sysfs, narrowed by the *_VISIBLE_DEVICES variables when they are set."""
+    n = 0
+    for props in Path("/sys/class/kfd/kfd/topology/nodes").glob("*/properties"):
+        try:
+            kv = dict(line.split(None, 1) for line in props.read_text().splitlines() if " " in line)
+            n += int(kv.get("simd_count", "0")) > 0
+        except Exception:
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([d for d in v.split(",") if d.strip() != ""]))
+    return n
+
+
 def maybe_launch_ranks(args):
-    """--gpus N > 1 without a torch.distributed.run environment: start N ranks as CHILD processes (this process
-    has not touched a GPU: torch.cuda.device_count() does not initialise HIP) and exit with their status."""
+    """--gpus N > 1 without a torch.distributed.run environment: start N ranks as CHILD processes (this process never
+    initialises HIP: devices are counted from sysfs) and exit with their status."""
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is not None:
         if int(env_world) != args.gpus:
@@ -111,8 +164,7 @@ def maybe_launch_ranks(args):
     if args.gpus <= 1:
         return
     if not args.dry_run_cpu:
-        import torch
-        have = torch.cuda.device_count()
+        have = visible_gpus()
         if have < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible HIP devices, found {have}; "
                              "refusing to report a multi-GPU number from fewer devices")
@@ -256,26 +308,136 @@ def dry_run_cpu(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def main():
-    args = parse_args()
-    maybe_launch_ranks(args)
-    if args.dry_run_cpu:
-        return dry_run_cpu(args)
-
+def roofline_leg(args, cfg, model, x, n_prof_small=10):
+    """Roofline of the LGSSM kernel chain: HIP events around each C-ABI call (on the launch stream), eager launches."""
     import torch
-    import torch.distributed as dist
     from kvae import _native
+    from kvae.train.train import Trainer
+    B, T = args.batch, args.seq_len
+    eager = Trainer(model, use_graph=False, world_size=1, reference_logging=True)   # takes the model over from the captured trainer
+    for _ in range(3):
+        eager.step(x)
+    n_prof = n_prof_small if B * T <= 20000 else 4
+    _native.profile_start()
+    for _ in range(n_prof):
+        eager.step(x)
+    times = _native.profile_stop()
+    q_per_step = args.dynamics == "switching"
+    per_unit = algorithmic_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, q_per_step)
+    per_unit.update(lstm_bytes(cfg.a_dim, cfg.dynamics_hidden_dim))
+    K = args.modes
+    per_unit.update({"regime_fwd": 4 * (K * K + 2 * K + 2), "regime_bwd": 4 * (2 * K * K + 3 * K + 2)})
+    chain = {}
+    for name, ms in times.items():
+        # a call may be issued as several chunked launches per step (VAE kernels above 16384 frames):
+        # account per STEP (sum of its launches), so that bytes / flop of the whole batch meet the whole time
+        launches = max(1, round(len(ms) / n_prof))
+        per_step_us = 1e3 * sum(ms) / n_prof
+        ent = {"avg_us": round(per_step_us / launches, 2), "launches_per_step": launches,
+               "per_step_us": round(per_step_us, 2)}
+        if name in per_unit:
+            nbytes = per_unit[name] * B * T
+            ent.update(algorithmic_bytes=nbytes, GBps=round(nbytes / (per_step_us * 1e-6) / 1e9, 2))
+            if name == "elbo":
+                ent["grad_output_bytes"] = elbo_grad_output_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, q_per_step) * B * T
+        chain[name] = ent
+    traffic, traffic_src = {}, None
+    try:   # HBM bytes per launch from the PMC passes committed under profiles/ (matching config only)
+        tj = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        key = f"B{B}_T{T}_n{cfg.z_dim}_{args.dynamics}_K{args.modes}"
+        if key in tj:
+            traffic = tj[key]
+            traffic_src = f"profiles/pmc_traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({tj.get('_round', '?')}), not measured in this run"
+    except Exception:
+        traffic = {}
+    roofline = None
+    lg = {k: v for k, v in chain.items() if k in ("smooth_fwd", "smooth_bwd", "elbo")}
+    if lg:
+        dom = max(lg, key=lambda k: lg[k]["per_step_us"])
+        ach = chain[dom]["GBps"]
+        n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
+        n16 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (16, 16, 2)
+        kname = {"smooth_fwd": "k_smooth_fwd_q4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
+                 "smooth_bwd": "k_smooth_bwd_q4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
+                 "elbo": "k_elbo_tpp(+probe)" if n4 else ("k_elbo4_n16 / k_elbo_n16 (+probe)" if n16 else "k_elbo(+probe)")}[dom]
+        roofline = {"kernel": kname,
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom), "traffic_source": traffic_src,
+                    "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["per_step_us"],
+                    "note": "T-deep dependent recursion, " + ("sixteen sequences" if n4 else "one sequence") +
+                            " per wavefront: latency-bound, not byte-bound, whenever the batch is far below the "
+                            "wave slots of the chip (" + ("B/16" if n4 else "B") + " wavefronts here)"}
+        # the kernel that dominates the STEP is outside the LGSSM path: the decoder 32->128 block on the f32 matrix cores
+        up = chain.get("dec_up_fwd_s8")
+        if up and (cfg.img_size, tuple(cfg.decoder_channels)) == (32, (32, 32, 32)):
+            wino = os.environ.get("KVAE_WINO", "1") != "0"
+            direct = 2.0 * B * T * 64 * 128 * 288          # MACs x 2: 64 pixels, 128 output channels, 32 x 9 taps
+            flop = direct / 2.25 if wino else direct       # Winograd F(2x2,3x3): 16 multiplies per 2x2 tile instead of 36
+            tf = flop / (up["per_step_us"] * 1e-6) / 1e12  # all chunk launches of the step together
+            roofline["step_dominant_kernel"] = {
+                "kernel": ("k_dec_up_fwd_wino<8> (conv 32->128 3x3 as Winograd F(2x2,3x3) + PixelShuffle + ReLU, exact-f32 MFMA)"
+                           if wino else "k_dec_up_fwd<8> (conv 32->128 3x3 + PixelShuffle + ReLU, exact-f32 MFMA)"),
+                "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_F32_PEAK_TFS, 4), "flop_per_step": flop, "launches_per_step": up["launches_per_step"],
+                "per_step_us": up["per_step_us"],
+                "note": ("flop = the matrix-core multiplies the kernel really issues (direct convolution / 2.25); "
+                         f"direct-convolution-equivalent rate {direct / (up['per_step_us'] * 1e-6) / 1e12:.0f} TFLOP/s; " if wino else "") +
+                        "its data-gradient and weight-gradient twins run within 20 % of the same rate (profiles/)"}
+        tot_us = sum(c["per_step_us"] for c in lg.values())
+        tot_b = sum(c["algorithmic_bytes"] for c in lg.values())
+        chain["chain_total"] = {"per_step_us": round(tot_us, 2), "algorithmic_bytes": tot_b,
+                                "GBps": round(tot_b / (tot_us * 1e-6) / 1e9, 2)}
+    return roofline, chain
+
+
+def impute_leg(args, cfg, model, x, steps):
+    """Eval-mode KVAE.impute (kvae/model/model.py:243-301 there: forward with the block mask of imputation.py:4-12, the two
+    emission read-outs, three decoder passes) - what BASELINE configs[3] checks; sequences/s, eager and hipGraph-replayed."""
+    import torch
+    from kvae.train.imputation import config_block_mask
+    B, T = x.shape[:2]
+    mask = config_block_mask(cfg, B, T, device=x.device)
+    was_training = model.training
+    out = {"mask": f"block: t_init {cfg.t_init_mask}, t_steps {cfg.t_steps_mask} (imputation.py:4-12)"}
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    s = timed(lambda: model.impute(x, mask), steps)
+    out["eager"] = {"ms_per_call": round(1e3 * s, 4), "sequences_per_s": round(B / s, 1)}
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model.impute(x, mask)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            model.impute(x, mask)
+        s = timed(graph.replay, steps)
+        out["hipgraph"] = {"ms_per_call": round(1e3 * s, 4), "sequences_per_s": round(B / s, 1)}
+        del graph
+    except Exception as e:   # report the eager figure only, and why
+        out["hipgraph"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    model.train(was_training)
+    return out
+
+
+def run_workload(args, dev, rank, world, full):
+    """One workload end to end: build, capture, time `args.steps` steps (barrier + device sync on both sides, max over ranks),
+    then - rank 0 - the extra legs.  full: steady-state windows and the CPU baseline at full budget (the headline);
+    otherwise a short version of each (the `also` entries of the default run)."""
+    import gc
+    import torch
     from kvae.train.synthetic import bouncing_ball
-    from kvae.train.train import Trainer, init_distributed
-    rank, world, dev = init_distributed()
-    if dev.type != "cuda":
-        raise SystemExit("bench.py needs a HIP device (the LGSSM path has no CPU fallback)")
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: world size {world} != --gpus {args.gpus}")
-    _native.hip_lib()
-    backend = dist.get_backend() if world > 1 else "none"
-    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)} (device {dev.index}), backend {backend} "
-        f"[nccl == RCCL on ROCm]; building model")
+    from kvae.train.train import Trainer
     cfg, model = build_model(args, dev)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     B, T = args.batch, args.seq_len
@@ -284,7 +446,7 @@ def main():
 
     capture = "hipgraph"
     mk_trainer = lambda graph, w=world, ov=not args.no_overlap: Trainer(
-        model, use_graph=graph, world_size=w, overlap_lgssm=ov, reference_logging=True)
+        model, use_graph=graph, world_size=w, overlap_lgssm=ov, reference_logging=True, graph_allreduce=args.graph_allreduce)
     trainer = mk_trainer(not args.no_graph)
     try:
         for _ in range(max(args.warmup, 1)):
@@ -301,21 +463,22 @@ def main():
             out = trainer.step(x)
     if args.no_graph:
         capture = "eager"
-    log(f"warm-up done ({capture}); timing {args.steps} steps")
+    log(f"[{args.config}] warm-up done ({capture}); timing {args.steps} steps")
 
     # ---- the timed region the contract defines: EXACTLY --steps steps --------------------------------------------
     elapsed, out = timed_window(trainer, x, args.steps, world, dev)
     loss = float(out["loss"])
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
-    log(f"timed region: {ms_per_step:.3f} ms/step, {value:.1f} seq/s")
+    log(f"[{args.config}] timed region: {ms_per_step:.3f} ms/step, {value:.1f} seq/s")
 
-    # ---- steady state: >= 5 further windows, >= 2 s or >= 200 steps in all; median and spread ----------------------
+    # ---- steady state: further windows (>= 5 and >= 2 s or >= 200 steps in all for the headline); median and spread ----
     steady = None
     if not args.no_steady:
         per = max(4, min(200, int(0.4 / max(ms_per_step * 1e-3, 1e-6)) + 1))   # ~0.4 s per window
+        min_wins, min_s, min_steps = (5, 2.0, 200) if full else (3, 0.6, 60)
         wins, total_steps, total_s = [], 0, 0.0
-        while len(wins) < 5 or (total_s < 2.0 and total_steps < 200):
+        while len(wins) < min_wins or (total_s < min_s and total_steps < min_steps):
             el, _ = timed_window(trainer, x, per, world, dev)
             wins.append(1e3 * el / per)
             total_steps += per
@@ -327,104 +490,90 @@ def main():
         steady = {"windows": len(wins), "steps_per_window": per, "total_steps": total_steps, "total_s": round(total_s, 3),
                   "ms_per_step_median": round(med, 4), "ms_per_step_min": round(sw[0], 4), "ms_per_step_max": round(sw[-1], 4),
                   "value_median": round(world * B / (med * 1e-3), 2)}
-        log(f"steady state: median {med:.3f} ms/step over {len(wins)} windows of {per} steps "
+        log(f"[{args.config}] steady state: median {med:.3f} ms/step over {len(wins)} windows of {per} steps "
             f"(min {sw[0]:.3f}, max {sw[-1]:.3f})")
 
-    # ---- roofline of the LGSSM kernel chain: HIP events around each C-ABI call, eager launches --------------------
-    roofline, chain = None, {}
+    roofline, chain, impute = None, {}, None
     if rank == 0 and not args.no_roofline:
-        eager = Trainer(model, use_graph=False, world_size=1, reference_logging=True)
-        for _ in range(3):
-            eager.step(x)
-        n_prof = 10 if B * T <= 20000 else 4
-        _native.profile_start()
-        for _ in range(n_prof):
-            eager.step(x)
-        times = _native.profile_stop()
-        q_per_step = args.dynamics == "switching"
-        per_unit = algorithmic_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, q_per_step)
-        per_unit.update(lstm_bytes(cfg.a_dim, cfg.dynamics_hidden_dim))
-        K = args.modes
-        per_unit.update({"regime_fwd": 4 * (K * K + 2 * K + 2), "regime_bwd": 4 * (2 * K * K + 3 * K + 2)})
-        for name, ms in times.items():
-            # a call may be issued as several chunked launches per step (VAE kernels above 16384 frames):
-            # account per STEP (sum of its launches), so that bytes / flop of the whole batch meet the whole time
-            launches = max(1, round(len(ms) / n_prof))
-            per_step_us = 1e3 * sum(ms) / n_prof
-            ent = {"avg_us": round(per_step_us / launches, 2), "launches_per_step": launches,
-                   "per_step_us": round(per_step_us, 2)}
-            if name in per_unit:
-                nbytes = per_unit[name] * B * T
-                ent.update(algorithmic_bytes=nbytes, GBps=round(nbytes / (per_step_us * 1e-6) / 1e9, 2))
-                if name == "elbo":
-                    ent["grad_output_bytes"] = elbo_grad_output_bytes(cfg.z_dim, cfg.u_dim, cfg.a_dim, q_per_step) * B * T
-            chain[name] = ent
-        traffic, traffic_src = {}, None
-        try:   # HBM bytes per launch from the PMC passes committed under profiles/ (matching config only)
-            tj = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-            key = f"B{B}_T{T}_n{cfg.z_dim}_{args.dynamics}_K{args.modes}"
-            if key in tj:
-                traffic = tj[key]
-                traffic_src = f"profiles/pmc_traffic.json[{key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({tj.get('_round', '?')}), not measured in this run"
-        except Exception:
-            traffic = {}
-        lg = {k: v for k, v in chain.items() if k in ("smooth_fwd", "smooth_bwd", "elbo")}
-        if lg:
-            dom = max(lg, key=lambda k: lg[k]["per_step_us"])
-            ach = chain[dom]["GBps"]
-            n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
-            n16 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (16, 16, 2)
-            kname = {"smooth_fwd": "k_smooth_fwd_q4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
-                     "smooth_bwd": "k_smooth_bwd_q4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
-                     "elbo": "k_elbo_tpp(+probe)" if n4 else "k_elbo(+probe)"}[dom]
-            roofline = {"kernel": kname,
-                        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic.get(dom), "traffic_source": traffic_src,
-                        "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["per_step_us"],
-                        "note": "T-deep dependent recursion, " + ("sixteen sequences" if n4 else "one sequence") +
-                                " per wavefront: latency-bound, not byte-bound, whenever the batch is far below the "
-                                "wave slots of the chip (" + ("B/16" if n4 else "B") + " wavefronts here)"}
-            # the kernel that dominates the STEP is outside the LGSSM path: the decoder 32->128 block on the f32 matrix cores
-            up = chain.get("dec_up_fwd_s8")
-            if up and (cfg.img_size, tuple(cfg.decoder_channels)) == (32, (32, 32, 32)):
-                wino = os.environ.get("KVAE_WINO", "1") != "0"
-                direct = 2.0 * B * T * 64 * 128 * 288          # MACs x 2: 64 pixels, 128 output channels, 32 x 9 taps
-                flop = direct / 2.25 if wino else direct       # Winograd F(2x2,3x3): 16 multiplies per 2x2 tile instead of 36
-                tf = flop / (up["per_step_us"] * 1e-6) / 1e12  # all chunk launches of the step together
-                roofline["step_dominant_kernel"] = {
-                    "kernel": ("k_dec_up_fwd_wino<8> (conv 32->128 3x3 as Winograd F(2x2,3x3) + PixelShuffle + ReLU, exact-f32 MFMA)"
-                               if wino else "k_dec_up_fwd<8> (conv 32->128 3x3 + PixelShuffle + ReLU, exact-f32 MFMA)"),
-                    "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_F32_PEAK_TFS, 4), "flop_per_step": flop, "launches_per_step": up["launches_per_step"],
-                    "per_step_us": up["per_step_us"],
-                    "note": ("flop = the matrix-core multiplies the kernel really issues (direct convolution / 2.25); "
-                             f"direct-convolution-equivalent rate {direct / (up['per_step_us'] * 1e-6) / 1e12:.0f} TFLOP/s; " if wino else "") +
-                            "its data-gradient and weight-gradient twins run within 20 % of the same rate (profiles/)"}
-            tot_us = sum(c["per_step_us"] for c in lg.values())
-            tot_b = sum(c["algorithmic_bytes"] for c in lg.values())
-            chain["chain_total"] = {"per_step_us": round(tot_us, 2), "algorithmic_bytes": tot_b,
-                                    "GBps": round(tot_b / (tot_us * 1e-6) / 1e9, 2)}
-
+        roofline, chain = roofline_leg(args, cfg, model, x, n_prof_small=10 if full else 5)
+    if rank == 0 and args.impute:
+        impute = impute_leg(args, cfg, model, x, steps=max(10, min(50, args.steps)))
+        log(f"[{args.config}] impute: {impute}")
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, sd_cpu, frames)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and (full or args.cpu_in_also):
+        cpu = cpu_baseline(args, sd_cpu, frames, budget_s=25.0 if full else 6.0)
+    res = {"value": round(value, 2), "ms_per_step": round(ms_per_step, 4), "steps": args.steps, "warmup": args.warmup,
+           "config": {"workload": workload_name(args, (cfg.z_dim, cfg.u_dim, cfg.a_dim)), "preset": args.config,
+                      "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}", "capture": capture,
+                      "final_loss": round(loss, 5)},
+           "steady_state": steady, "roofline": roofline, "lgssm_chain": chain, "cpu_baseline": cpu}
+    if impute is not None:
+        res["impute"] = impute
+    if cpu:
+        res["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    del trainer, model, x
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse_args()
+    maybe_launch_ranks(args)
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
+
+    import copy
+    import torch
+    import torch.distributed as dist
+    from kvae import _native
+    from kvae.train.train import init_distributed
+    rank, world, dev = init_distributed()
+    if dev.type != "cuda":
+        raise SystemExit("bench.py needs a HIP device (the LGSSM path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: world size {world} != --gpus {args.gpus}")
+    _native.hip_lib()
+    backend = dist.get_backend() if world > 1 else "none"
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(dev)} (device {dev.index}), backend {backend} "
+        f"[nccl == RCCL on ROCm]")
+    res = run_workload(args, dev, rank, world, full=True)
+
+    # ---- the other BASELINE configs under the same clock: short runs appended as `also` (default invocation only) ----------
+    also = {}
+    if args.also:
+        for name in args.also:
+            a = copy.copy(args)
+            for k in ("batch", "seq_len", "z_dim", "dynamics", "modes"):
+                setattr(a, k, None)
+            a.config = name
+            apply_preset(a)
+            a.steps, a.warmup = ALSO_STEPS.get(name, 30), 5
+            a.impute = PRESETS[name].get("impute", False)
+            a.cpu_in_also = name.startswith("c4")   # seconds at B = 32; the stress shard's CPU leg is minutes: `--config c5` has it
+            t0 = time.perf_counter()
+            r = run_workload(a, dev, rank, world, full=False)
+            r["wall_s"] = round(time.perf_counter() - t0, 1)
+            also[name] = r
 
     if rank == 0:
         line = {
-            "metric": "sequences/sec (ELBO training step, 32x32xT bouncing-ball)", "value": round(value, 2),
+            "metric": "sequences/sec (ELBO training step, 32x32xT bouncing-ball)", "value": res["value"],
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_name(args, (cfg.z_dim, cfg.u_dim, cfg.a_dim)), "preset": args.config,
-                       "global_batch": world * B, "seq_len": T, "parallelism": f"dp{world}", "capture": capture,
-                       "dist_backend": backend, "final_loss": round(loss, 5)},
-            "steady_state": steady,
-            "roofline": roofline, "lgssm_chain": chain, "cpu_baseline": cpu,
+            "config": dict(res["config"], dist_backend=backend),
+            "steady_state": res["steady_state"],
+            "roofline": res["roofline"], "lgssm_chain": res["lgssm_chain"], "cpu_baseline": res["cpu_baseline"],
         }
-        if cpu:
-            line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        for k in ("impute", "speedup_vs_cpu_baseline"):
+            if k in res:
+                line[k] = res[k]
+        if also:
+            line["also"] = also
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 ran the extra legs alone: nobody tears the process group down under it
         dist.destroy_process_group()
 
 

@@ -146,7 +146,9 @@ int kvae_lgssm_alpha_lstm_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_s
  * 0..4 (jitter 1e-6 * 10^level) at which every factorisation succeeds, or 5 = diagonal fallback.
  * If `g` / g_mus / g_Sigmas are non-NULL the gradients of SUM(terms) w.r.t. mus_smooth,
  * Sigmas_smooth and the problem inputs are written as well (unit upstream; the caller scales).
- * eps: [B,T,n] standard normal draws. chol_levels: 2 ints of device scratch (zeroed by the call).
+ * eps: [B,T,n] standard normal draws. chol_levels: 3 ints of device memory (zeroed by the call); [2] receives the kernel family
+ * the main launch ran (0 wave-per-step generic, 1 thread-per-step (4,4,2), 2 / 3 the (16,16,2) matrix-core kernels with one /
+ * four steps per wavefront) - all families take every level.
  * ws_lz: optional scratch [B,T,n]: the probe launch parks its level-0 sample z_t there so that the main launch does not
  * re-factorise the neighbouring steps (NULL = always recompute). */
 int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, const float *Sigmas_smooth,
@@ -282,7 +284,7 @@ int64_t kvae_rnn_wgrad_ws_floats(const kvae_wgrad_problem *probs, int32_t n);
 int kvae_rnn_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, void *stream);
 
 /* y[N,O] = x[N,F] W[O,F]^T + b (b may be NULL); softmax != 0: softmax over the O <= 16 outputs fused (head_w + softmax,
- * dyn_param.py:53-56).  x rows are x_stride floats apart.  F <= 128, O*F <= 16384. */
+ * dyn_param.py:53-56).  x rows are x_stride floats apart.  F <= 128, O*F <= 12288. */
 int kvae_linear_fwd(const float *x, int64_t x_stride, int64_t N, int32_t F, const float *W, const float *b, int32_t O,
                     int32_t softmax, float *y, void *stream);
 /* dx[N,F] = gl W with gl = g, or - when y (the softmax output of the forward) is given - gl = y * (g - <g, y>), which is then

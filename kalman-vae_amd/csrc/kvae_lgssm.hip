@@ -386,7 +386,7 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
   const bool want_g = (g_mus != nullptr);
   if (want_g && (!g_Sigmas || !g || !g->gA.ptr || !g->gB.ptr || !g->gC.ptr || !g->gY)) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(chol_levels, 0, 2 * sizeof(int32_t), s) != hipSuccess) return launch_status("memset chol_levels");
+  if (hipMemsetAsync(chol_levels, 0, 3 * sizeof(int32_t), s) != hipSuccess) return launch_status("memset chol_levels");
   const unsigned grid = (unsigned)((int64_t)prob->B * prob->T);
   kvae_lgssm_input_grads gz;
   memset(&gz, 0, sizeof(gz));
@@ -405,17 +405,14 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
       (!want_g || (aligned16(g_Sigmas) && aligned16(g->gA.ptr) && g->gA.sb % 4 == 0 && g->gA.st % 4 == 0 && aligned16(g->gB.ptr) &&
                    g->gB.sb % 4 == 0 && g->gB.st % 4 == 0))) {
     // matrix-core / four-matrices-per-wavefront kernels (lgssm_n16_elbo.h): the probe resolves the jitter levels with the
-    // generic semantics; the fast main launch computes the call when both are 0, the generic one when they are not
+    // generic semantics (and re-samples z at a raised level of Sigma_s); the main launch computes the call at whatever the
+    // levels are - jitter ladder and diagonal fallback included, no generic backup launch
     kvae_n16_launch_elbo_probe(prob, Sigmas_smooth, mus_smooth, eps, ws_lz, chol_levels, s);
     rc = launch_status("k_elbo_probe_n16");
     if (rc) return rc;
     kvae_n16_launch_elbo(prob, mus_smooth, Sigmas_smooth, eps, terms, chol_levels, ws_lz, g_mus, g_Sigmas, want_g ? g : &gz,
                          want_g ? 1 : 0, s);
-    rc = launch_status("k_elbo_n16");
-    if (rc) return rc;
-    k_elbo<SDims<16, 16, 2>><<<dim3(grid < 4096 ? grid : 4096), dim3(64), 0, s>>>(*prob, mus_smooth, Sigmas_smooth, eps, terms, (const int32_t *)chol_levels,
-                                                            nullptr, g_mus, g_Sigmas, want_g ? *g : gz, want_g ? 1 : 0, 1);
-    return launch_status("k_elbo(jitter fallback)");
+    return launch_status("k_elbo_n16");
   }
   KVAE_DISPATCH(*prob, k_elbo_probe<D><<<dim3(grid), dim3(64), 0, s>>>(*prob, Sigmas_smooth, mus_smooth, eps, ws_lz, chol_levels));
   rc = launch_status("k_elbo_probe");
@@ -561,14 +558,14 @@ int kvae_rnn_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, void *
 int kvae_linear_fwd(const float *x, int64_t x_stride, int64_t N, int32_t F, const float *W, const float *b, int32_t O,
                     int32_t softmax, float *y, void *stream) {
   if (!x || !W || !y) return KVAE_ERR_NULL;
-  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (softmax && O > 16)) return KVAE_ERR_DIMS;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 12288 || (softmax && O > 16)) return KVAE_ERR_DIMS;
   kvae_rnn_launch_linear_fwd(x, x_stride, N, F, W, b, O, softmax, y, (hipStream_t)stream);
   return launch_status("k_linear_fwd");
 }
 int kvae_linear_bwd_input(const float *g, const float *y, int64_t N, int32_t F, const float *W, int32_t O, float *g_logit,
                           float *dx, int64_t dx_stride, void *stream) {
   if (!g || !W || !dx || (y && !g_logit)) return KVAE_ERR_NULL;
-  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (y && O > 16)) return KVAE_ERR_DIMS;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 12288 || (y && O > 16)) return KVAE_ERR_DIMS;
   kvae_rnn_launch_linear_bwd_input(g, y, N, F, W, O, g_logit, dx, dx_stride, (hipStream_t)stream);
   return launch_status("k_linear_bwd_input");
 }

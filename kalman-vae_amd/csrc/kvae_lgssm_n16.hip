@@ -88,6 +88,14 @@ __global__ __launch_bounds__(64) void k_elbo4_n16(kvae_lgssm_problem P, const fl
   const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
   n16::elbo_main4<GRADS>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t0, L);
 }
+// z_t again at the resolved level of Sigma_s (lgssm_n16_elbo.h, elbo_zfix); grid = B * ceil(T / 4), every wavefront leaves at its
+// first instruction when that level is 0
+__global__ __launch_bounds__(64) void k_elbo_zfix_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
+                                                      float *zst, const int32_t *levels) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
+  n16::elbo_zfix(P, Sig_s, mus, eps, zst, levels, b, t0);
+}
 static bool elbo_shared_q(const kvae_lgssm_problem *p) {
   static const int env = getenv("KVAE_ELBO4") ? atoi(getenv("KVAE_ELBO4")) : 1;   // 0: one step per wavefront (A/B runs)
   return env != 0 && p->Q.sb == 0 && p->Q.st == 0;
@@ -97,9 +105,10 @@ extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const fl
                                            float *zst, int32_t *levels, hipStream_t s) {
   if (elbo_shared_q(p)) {
     k_elbo_probe4_n16<<<dim3((unsigned)((int64_t)p->B * ((p->T + 3) / 4))), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
-    return;
+  } else {
+    k_elbo_probe_n16<<<dim3((unsigned)((int64_t)p->B * p->T)), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
   }
-  k_elbo_probe_n16<<<dim3((unsigned)((int64_t)p->B * p->T)), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
+  k_elbo_zfix_n16<<<dim3((unsigned)((int64_t)p->B * ((p->T + 3) / 4))), dim3(64), 0, s>>>(*p, Sig_s, mus, eps, zst, levels);
 }
 extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
                                      float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,

@@ -46,8 +46,10 @@ extern "C" int kvae_rnn_launch_wgrad(const kvae_wgrad_problem *probs, int32_t n,
     max_n = p.N > max_n ? p.N : max_n;
     max_elems = (int64_t)p.R * C > max_elems ? (int64_t)p.R * C : max_elems;
   }
-  // split-K: enough chunks to fill the chip, at least 16 rows (four k-steps) each
-  int chunks = (int)((max_n + 15) / 16);
+  // split-K: about two workgroups per CU over all problems and column groups, at least one 32-row stage each
+  int chunks = (int)((max_n + 31) / 32);
+  const int fill = 512 / (n * max_groups);
+  chunks = chunks > fill ? fill : chunks;
   chunks = chunks > WG_MAX_CHUNKS ? WG_MAX_CHUNKS : (chunks < 1 ? 1 : chunks);
   const int64_t stride = per * WG_MAX_CHUNKS;
   const dim3 grid((unsigned)chunks, (unsigned)max_groups, (unsigned)n), block(256);
@@ -56,30 +58,30 @@ extern "C" int kvae_rnn_launch_wgrad(const kvae_wgrad_problem *probs, int32_t n,
   else if (max_rt <= 10) k_rnn_wgrad_partial<10><<<grid, block, 0, s>>>(batch, ws, stride, chunks);
   else if (max_rt <= 13) k_rnn_wgrad_partial<13><<<grid, block, 0, s>>>(batch, ws, stride, chunks);
   else k_rnn_wgrad_partial<16><<<grid, block, 0, s>>>(batch, ws, stride, chunks);
-  k_rnn_wgrad_final<<<dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), block, 0, s>>>(batch, ws, stride, chunks);
+  k_rnn_wgrad_final<<<dim3((unsigned)((max_elems + 31) / 32), (unsigned)n), block, 0, s>>>(batch, ws, stride, chunks);
   return KVAE_OK;
 }
 
 extern "C" int kvae_rnn_launch_linear_fwd(const float *x, int64_t xs, int64_t N, int F, const float *W, const float *b, int O,
                                           int softmax, float *y, hipStream_t s) {
-  const size_t lds = sizeof(float) * O * F;
-  if (softmax) {
-    k_linear_softmax_fwd<<<dim3((unsigned)((N + 255) / 256)), dim3(256), lds, s>>>(x, xs, N, F, W, b, O, y);
-  } else {
-    const int64_t threads = N * ((O + 3) / 4);
-    k_linear_fwd<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s>>>(x, xs, N, F, W, b, O, y);
-  }
+  const int rows = sl_rows_per_block(F, O);
+  const size_t lds = sizeof(float) * ((size_t)O * F + (size_t)rows * (F + 1));
+  const dim3 grid((unsigned)((N + rows - 1) / rows));
+  if (softmax)
+    k_linear_softmax_fwd<<<grid, dim3(256), lds, s>>>(x, xs, N, F, W, b, O, y, rows);
+  else
+    k_linear_fwd<<<grid, dim3(256), lds, s>>>(x, xs, N, F, W, b, O, y, rows);
   return KVAE_OK;
 }
 
 extern "C" int kvae_rnn_launch_linear_bwd_input(const float *g, const float *y, int64_t N, int F, const float *W, int O,
                                                 float *g_logit, float *dx, int64_t dxs, hipStream_t s) {
   const size_t lds = sizeof(float) * O * F;
-  if (y) {
-    k_linear_softmax_bwd_input<<<dim3((unsigned)((N + 255) / 256)), dim3(256), lds, s>>>(g, y, N, F, W, O, g_logit, dx, dxs);
-  } else {
-    const int64_t threads = N * ((F + 3) / 4);
-    k_linear_bwd_input<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, s>>>(g, N, F, W, O, dx, dxs);
-  }
+  const int64_t threads = N * ((F + 3) / 4);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (y)
+    k_linear_softmax_bwd_input<<<grid, dim3(256), lds, s>>>(g, y, N, F, W, O, g_logit, dx, dxs);
+  else
+    k_linear_bwd_input<<<grid, dim3(256), lds, s>>>(g, N, F, W, O, dx, dxs);
   return KVAE_OK;
 }

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64) void k_elbo_tpp(kvae_lgssm_problem P, const flo
                                                  float *terms, const int32_t *levels, const float *ws, float *g_mus,
                                                  float *g_Sigs, kvae_lgssm_input_grads G, int have_g) {
   const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (q == 0) const_cast<int32_t *>(levels)[2] = 1;   // kernel family of this launch (include/kvae_lgssm.h: chol_levels[2])
   if (q >= (int64_t)P.B * P.T) return;
   ElboLds<D> L;
   const D d(P.n, P.m, P.p);

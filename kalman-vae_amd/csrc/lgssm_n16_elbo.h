@@ -12,8 +12,12 @@
 //
 // _safe_cholesky (kalman_filter.py:282-302): the probe launch resolves the whole-batch jitter level exactly as the generic
 // probe does (first level 0..4 whose factorisation has all pivots > 0, 5 = diagonal fallback) and parks z_t = mu_t + L_t eps_t
-// of level 0.  The main launch below handles level 0 for both families - the case of every sane model - and returns at once
-// otherwise; kvae_lgssm_elbo then runs the generic main kernel, which in turn returns at once when both levels are 0.
+// of level 0.  A raised level is the same factorisation of sym(X) + 1e-6 * 10^level I, and the diagonal fallback is the
+// factorisation of diag(max(X_ii, 1e-6)) - so the main launches below take EVERY level (round 2 handed levels > 0 to the
+// generic one-lane kernel: 3.3 ms instead of 0.4 at the configs[4] shard, and a learned Q[K,n,n] makes a raised level an
+// ordinary event for the switching model): the matrix a row-group factorises is prepared according to its family's level, the
+// instruction stream stays the same.  Only two things differ at level 5: the gradient reaches the un-clamped diagonal alone
+// (sqrt(clamp(diag)) has no other inputs), and - at any level > 0 of Sigma_s - the parked z_t are redone first (elbo_zfix).
 #pragma once
 #include "lgssm_elbo.h"
 #include "lgssm_n16.h"
@@ -140,6 +144,28 @@ __device__ __forceinline__ void identity_rows(float (&m)[N], int i) {
 #pragma unroll
   for (int c = 0; c < N; ++c) m[c] = c == i ? 1.0f : 0.0f;
 }
+__device__ __forceinline__ float diag_of_rows(const float (&m)[N], int i) {
+  float d = 0.0f;
+#pragma unroll
+  for (int c = 0; c < N; ++c) d = c == i ? m[c] : d;
+  return d;
+}
+// Row i of the matrix _safe_cholesky factorises at `level` (kalman_filter.py:286-302): sym(X) + 1e-6 * 10^level I for levels
+// 0..4; at level 5 (no jitter repaired the batch) the factor is diag(sqrt(clamp(diag X, 1e-6))), i.e. the Cholesky factor of
+// the diagonal matrix returned here.  `raw_diag` receives X_ii (the level-5 gradient only flows where X_ii >= 1e-6).
+__device__ __forceinline__ void load_level_rows(const float *X, float (&m)[N], int i, int level, float &raw_diag) {
+  load_sym_rows(X, m, i, 0.0f, false);
+  raw_diag = diag_of_rows(m, i);
+  const float jit = jitter_of_level(level < 5 ? level : 0);
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const float lv = m[c] + (c == i ? jit : 0.0f);
+    const float dg = c == i ? fmaxf(raw_diag, 1e-6f) : 0.0f;
+    m[c] = level >= 5 ? dg : lv;
+  }
+}
+// kernel families of the ELBO main launch, written to chol_levels[2] by the launch itself (tests assert which one ran)
+enum : int { KV_ELBO_FAMILY_GENERIC = 0, KV_ELBO_FAMILY_TPP = 1, KV_ELBO_FAMILY_N16_STEP = 2, KV_ELBO_FAMILY_N16_FOUR = 3 };
 
 // acc = sum_c M[i][c] v[c] with row i of M on the lane (16-byte loads) and v in L-layout
 template <int C>
@@ -204,12 +230,33 @@ __device__ __forceinline__ void elbo_probe(const kvae_lgssm_problem &P, const fl
   if (i == 0 && g == 1 && lv > 0) atomic_max_i32(levels + 1, lv);
 }
 
+// ---- z_t again at the level the whole batch resolved to: only when Sigma_s left level 0 (the probe parked level-0 samples) ----
+// Four steps per wavefront (group g: step t0 + g); every wavefront returns at its first instruction in the normal case.
+__device__ __forceinline__ void elbo_zfix(const kvae_lgssm_problem &P, const float *Sig_s, const float *mus, const float *eps,
+                                          float *zst, const int32_t *levels, int b, int t0) {
+  const int lvS = levels[0];
+  if (lvS == 0) return;
+  const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int t = t0 + g;
+  const bool valid = t < P.T;
+  const int64_t q = (int64_t)b * P.T + (valid ? t : P.T - 1);
+  float m[N], raw;
+  load_level_rows(Sig_s + q * NN, m, i, lvS, raw);
+  Chol c;
+  cholesky_rows(m, c, i);
+  float epsL = eps[q * N + i];
+  float acc = mus[q * N + i];
+  dpp_guard(epsL);
+  lower_matvec_acc<0>(acc, c, epsL, i);
+  if (valid) zst[q * N + i] = acc;
+}
+
 // ---- main: the four terms of step (b,t) and, with GRADS, every gradient of SUM(terms) (unit upstream) --------------
 template <bool GRADS, bool HAS_GQ>
 __device__ __forceinline__ void elbo_main(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps,
                                           float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
                                           const kvae_lgssm_input_grads &G, int b, int t, ELds &L) {
-  if (levels[0] != 0 || levels[1] != 0) return;   // jittered batch: the generic kernel computes this call
+  const int lvS = levels[0], lvQ = levels[1];      // whole-batch levels of _safe_cholesky (probe launch): 0..4 jitter, 5 diagonal
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, T = P.T;
   const int64_t bT = (int64_t)b * T, q = bT + t;
   const bool has_prev = t >= 1, has_next = t + 1 < T;
@@ -219,11 +266,17 @@ __device__ __forceinline__ void elbo_main(const kvae_lgssm_problem &P, const flo
   if (g == 1 && has_prev) X = stack_at(P.Q, b, t);
   if (g == 2 && has_next) X = stack_at(P.Q, b, t + 1);
   if (g == 3 && t == 0) X = P.Sigma0 + (int64_t)b * P.Sigma0_sb;
-  float m[N];
-  load_sym_rows(X, m, i, g == 3 ? 0.0f : 1e-6f, g == 3);   // level 0 of _safe_cholesky; Sigma0 as MultivariateNormal takes it
+  float m[N], raw_diag;
+  if (g == 3) {                                    // Sigma0 as MultivariateNormal(covariance_matrix=...) takes it: no jitter
+    load_sym_rows(X, m, i, 0.0f, true);
+    raw_diag = 1.0f;
+  } else {
+    load_level_rows(X, m, i, g == 0 ? lvS : lvQ, raw_diag);
+  }
   if (!valid) identity_rows(m, i);
   Chol c;
   cholesky_rows(m, c, i);
+  if (blockIdx.x == 0 && lane == 0) const_cast<int32_t *>(levels)[2] = KV_ELBO_FAMILY_N16_STEP;
   // ---- z, operands, residuals: wv (g0), d_t (g1), d_{t+1} (g2), z_0 - mu0 (g3) ----
   const float zt = zst[q * N + i];
   const float zp = has_prev ? zst[(q - 1) * N + i] : 0.0f, zn = has_next ? zst[(q + 1) * N + i] : 0.0f;
@@ -295,22 +348,39 @@ __device__ __forceinline__ void elbo_main(const kvae_lgssm_problem &P, const flo
     __syncthreads();
     rows_to_tile(xr, L.t[g], i);
     __syncthreads();
-    const f4 Xs = tile_c(L.t[0], i, g);
-    const f4 epsW = load_w(eps + q * N, g);
     const float epsL = eps[q * N + i];
-    f4 Pht;                                                      // C-layout of Phi^T: [4g+r][i] = Phi[i][4g+r]
+    if (lvS >= 5) {   // (uniform) diagonal fallback: L = diag(sqrt(clamp(diag Sigma_s))), the gradient reaches the un-clamped diagonal only
+      const float ls = __shfl(c.ld, i, 64), rawS = __shfl(raw_diag, i, 64);
+      const float dv = rawS >= 1e-6f ? (gz * epsL + 1.0f / ls) / (2.0f * ls) : 0.0f;
+      f4 dg;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col = 4 * g + r;
-      Pht[r] = col < i ? aL * epsW[r] : (col == i ? 0.5f * (aL * epsL + 1.0f) : 0.0f);
+      for (int r = 0; r < 4; ++r) dg[r] = 4 * g + r == i ? dv : 0.0f;
+      store_rows(g_Sigs + q * NN, dg, i, g);
+    } else {
+      const f4 Xs = tile_c(L.t[0], i, g);
+      const f4 epsW = load_w(eps + q * N, g);
+      f4 Pht;                                                      // C-layout of Phi^T: [4g+r][i] = Phi[i][4g+r]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 4 * g + r;
+        Pht[r] = col < i ? aL * epsW[r] : (col == i ? 0.5f * (aL * epsL + 1.0f) : 0.0f);
+      }
+      const f4 PX = mtn(Pht, Xs);                                  // Phi L^{-1}
+      const f4 S = mtn(Xs, PX);                                    // L^{-T} Phi L^{-1}
+      store_rows(g_Sigs + q * NN, symmetrise(S, L.s, i, g), i, g);
     }
-    const f4 PX = mtn(Pht, Xs);                                  // Phi L^{-1}
-    const f4 S = mtn(Xs, PX);                                    // L^{-T} Phi L^{-1}
-    store_rows(g_Sigs + q * NN, symmetrise(S, L.s, i, g), i, g);
-    if constexpr (HAS_GQ) {   // gQ_t = 1/2 v v^T - 1/2 (L_Q L_Q^T)^{-1}
-      const f4 Xq = tile_c(L.t[1], i, g);
-      const f4 Qi = mtn(Xq, Xq);
-      const f4 gq = has_prev ? 0.5f * (vtW * vtL - Qi) : zero4();
+    if constexpr (HAS_GQ) {
+      f4 gq = zero4();
+      if (lvQ >= 5) {   // (uniform) log N(d; 0, diag l^2): d/dl_i = -1/l_i + d_i^2 / l_i^3, dl_i/dq_ii = 1/(2 l_i) where q_ii >= 1e-6
+        const float lq = __shfl(c.ld, 16 + i, 64), rawQ = __shfl(raw_diag, 16 + i, 64), dq = __shfl(rhs, 16 + i, 64);
+        const float dv = (has_prev && rawQ >= 1e-6f) ? (-1.0f / lq + dq * dq / (lq * lq * lq)) / (2.0f * lq) : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gq[r] = 4 * g + r == i ? dv : 0.0f;
+      } else {          // gQ_t = 1/2 v v^T - 1/2 (L_Q L_Q^T)^{-1}
+        const f4 Xq = tile_c(L.t[1], i, g);
+        const f4 Qi = mtn(Xq, Xq);
+        gq = has_prev ? 0.5f * (vtW * vtL - Qi) : zero4();
+      }
       store_c(gstack_at(G.gQ, b, t), gq, i, g);
     }
   }
@@ -389,8 +459,9 @@ template <bool GRADS>
 __device__ __forceinline__ void elbo_main4(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps,
                                            float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
                                            const kvae_lgssm_input_grads &G, int b, int t0, ELds4 &L) {
-  if (levels[0] != 0 || levels[1] != 0) return;   // jittered batch: the generic kernel computes this call
+  const int lvS = levels[0], lvQ = levels[1];      // whole-batch levels of _safe_cholesky (probe launch): 0..4 jitter, 5 diagonal
   const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, T = P.T;
+  if (blockIdx.x == 0 && lane == 0) const_cast<int32_t *>(levels)[2] = KV_ELBO_FAMILY_N16_FOUR;
   const int tr = t0 + g;
   const bool valid = tr < T;
   const int t = valid ? tr : T - 1;                // clamped: invalid groups recompute the last step and store nothing
@@ -399,8 +470,8 @@ __device__ __forceinline__ void elbo_main4(const kvae_lgssm_problem &P, const fl
   // ---- the shared Q: X = (chol(Q + 1e-6 I))^-1 and X^T, rows on lanes; log-determinant ----
   float xq[N], xqt[N], logdetQ;
   {
-    float mq[N];
-    load_sym_rows(P.Q.ptr, mq, i, 1e-6f, false);
+    float mq[N], rawq;
+    load_level_rows(P.Q.ptr, mq, i, lvQ, rawq);
     Chol cq;
     cholesky_rows(mq, cq, i);
     inverse_rows(cq, xq, i);
@@ -414,8 +485,8 @@ __device__ __forceinline__ void elbo_main4(const kvae_lgssm_problem &P, const fl
     for (int k = 0; k < N; ++k) xq[k] = k <= i ? xq[k] : 0.0f;
   }
   // ---- Sigma_s[t] of this group ----
-  float m[N];
-  load_sym_rows(Sigs + q * NN, m, i, 1e-6f, false);
+  float m[N], raw_diag;
+  load_level_rows(Sigs + q * NN, m, i, lvS, raw_diag);
   Chol c;
   cholesky_rows(m, c, i);
   const float zt = zst[q * N + i];
@@ -499,6 +570,20 @@ __device__ __forceinline__ void elbo_main4(const kvae_lgssm_problem &P, const fl
     rows_to_tile(xr, L.xt[g], i);
     L.gz[g][i] = gz;
     __syncthreads();
+    if (lvS >= 5) {   // (uniform) diagonal fallback: the gradient reaches the un-clamped diagonal of this group's Sigma_s only
+      const float dv = raw_diag >= 1e-6f ? (gz * eps[q * N + i] + 1.0f / c.ld) / (2.0f * c.ld) : 0.0f;
+      if (valid) {
+        float *gS = g_Sigs + q * NN + i * N;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          f4 dg;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dg[r] = 4 * k4 + r == i ? dv : 0.0f;
+          *reinterpret_cast<f4 *>(gS + 4 * k4) = dg;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
       if (t0 + gg >= T) break;                                    // wave-uniform

@@ -204,7 +204,7 @@ class KalmanFilter(nn.Module):
         if eps is None:
             eps = torch.randn(Bsz, T, self.n, device=y_t.device, dtype=y_t.dtype)
         eps = eps.to(device=y_t.device, dtype=y_t.dtype)
-        total, self.last_elbo_terms = LgssmElbo.apply(mu_t_T, Sigma_t_T, eps, y_t, u_t, mask, rec, A, Bm, Cm, Q,
+        total, self.last_elbo_terms, self.last_chol_levels = LgssmElbo.apply(mu_t_T, Sigma_t_T, eps, y_t, u_t, mask, rec, A, Bm, Cm, Q,
                                                       self.R, self.mu0, self.Sigma0, slots)
         if self.dyn_params.is_switching_dynamics:
             log_q, log_p = self.dyn_params.elbo_terms()

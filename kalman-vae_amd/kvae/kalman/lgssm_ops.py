@@ -195,9 +195,10 @@ class LgssmSmooth(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 class LgssmElbo(torch.autograd.Function):
     """The LGSSM terms of KalmanFilter.elbo (reference kalman_filter.py:347-389), summed over B and T.
-    Returns (total, per_term[4]); gradients are produced in the forward launch (unit upstream) and
-    scaled by the incoming scalar gradient in backward."""
-    last_chol_levels = None
+    Returns (total, per_term[4], levels int32[3]); gradients are produced in the forward launch (unit upstream) and
+    scaled by the incoming scalar gradient in backward.  levels (device, no host sync): the whole-batch _safe_cholesky level
+    the launch resolved for Sigma_s and for Q_t (0..4 = jitter 1e-6 * 10^level, 5 = diagonal fallback) and the kernel family
+    that computed the call (include/kvae_lgssm.h)."""
 
     @staticmethod
     def forward(ctx, mus, Sigs, eps, Y, U, mask, packed, A, Bm, Cm, Q, R, mu0, Sigma0, slots):
@@ -207,7 +208,7 @@ class LgssmElbo(torch.autograd.Function):
         mus_c = _f32c(mus.reshape(Bsz, T, n))
         Sigs_c, eps_c = _f32c(Sigs), _f32c(eps)
         terms = torch.empty(Bsz, T, 4, device=dev, dtype=torch.float32)
-        levels = torch.empty(2, device=dev, dtype=torch.int32)
+        levels = torch.empty(3, device=dev, dtype=torch.int32)   # (level of Sigma_s, level of Q_t, kernel family of the launch)
         ws_lz = torch.empty(Bsz, T, n, device=dev, dtype=torch.float32)   # z_t parked by the probe launch
         want = any(ctx.needs_input_grad)
         g_mus = g_Sigs = sink = None
@@ -221,14 +222,12 @@ class LgssmElbo(torch.autograd.Function):
             N.ptr(g_Sigs), C.byref(sink.g) if sink else None, call.stream)), "kvae_lgssm_elbo")
         per_term = terms.sum((0, 1))
         ctx.sink, ctx.g_mus, ctx.g_Sigs, ctx.mus_shape = sink, g_mus, g_Sigs, mus.shape
-        ctx.chol_levels = levels
-        LgssmElbo.last_chol_levels = levels   # device int32[2] (Sigma_s, Q_t): level of _safe_cholesky's ladder, 5 = diagonal
-        ctx.mark_non_differentiable(per_term)
+        ctx.mark_non_differentiable(per_term, levels)
         ctx.set_materialize_grads(False)
-        return per_term.sum(), per_term
+        return per_term.sum(), per_term, levels
 
     @staticmethod
-    def backward(ctx, g_total, _g_terms):
+    def backward(ctx, g_total, _g_terms, _g_levels):
         if g_total is None:
             return (None,) * 15
         sink, need = ctx.sink, ctx.needs_input_grad
@@ -320,7 +319,7 @@ def rnn_wgrad(ref, problems):
 
 def small_linear_supported(x, weight, softmax=False):
     O, F = weight.shape
-    return (N.fused_ok(x) and x.dtype == torch.float32 and weight.dtype == torch.float32 and F <= 128 and O * F <= 16384
+    return (N.fused_ok(x) and x.dtype == torch.float32 and weight.dtype == torch.float32 and F <= 128 and O * F <= 12288
             and (not softmax or O <= 16) and x.shape[-1] == F and x.stride(-1) == 1
             and (x.dim() == 2 or x.is_contiguous()))
 

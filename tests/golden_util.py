@@ -85,5 +85,8 @@ def stability_state_dict(kind, K, n=4, p=2):
 
 
 # round-2 fixtures (tests/golden/make_goldens_r2.py): (name, expected [level Sigma_s, level Q_t]); 5 = diagonal fallback
-JITTER_CASES = [("jitter_q_level1", [0, 1]), ("jitter_sigma_level2", [2, 0]), ("jitter_diag_fallback", [0, 5])]
+JITTER_CASES = [("jitter_q_level1", [0, 1]), ("jitter_sigma_level2", [2, 0]), ("jitter_diag_fallback", [0, 5]),
+                # round 3, z_dim = 16 (tests/golden/make_goldens_r3.py): the shape of the matrix-core ELBO kernels
+                ("jitter_n16_q_level1", [0, 1]), ("jitter_n16_sigma_level2", [2, 0]), ("jitter_n16_diag_fallback", [0, 5]),
+                ("jitter_n16_sigma_diag_fallback", [5, 0])]
 JITTER_GRADS = ["mu_s", "Sig_s", "a", "A_list", "B_list", "C_list", "Q_list"]

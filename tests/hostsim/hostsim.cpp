@@ -153,6 +153,7 @@ int kvae_lgssm_elbo(const kvae_lgssm_problem *prob, const float *mus_smooth, con
   if (rc) return rc;
   if (!mus_smooth || !Sigmas_smooth || !eps || !terms || !chol_levels) return KVAE_ERR_NULL;
   if (g_mus && (!g_Sigmas || !g || !g->gA.ptr || !g->gB.ptr || !g->gC.ptr || !g->gY)) return KVAE_ERR_NULL;
+  chol_levels[2] = 0;   // kernel family: the generic bodies
   KVAE_DISPATCH(*prob, (run_elbo<D>(*prob, mus_smooth, Sigmas_smooth, eps, terms, chol_levels, ws_lz, g_mus, g_Sigmas, g)));
   return KVAE_OK;
 }
@@ -797,7 +798,7 @@ int kvae_rnn_wgrad(const kvae_wgrad_problem *probs, int32_t n, float *ws, void *
 int kvae_linear_fwd(const float *x, int64_t xs, int64_t N, int32_t F, const float *W, const float *b, int32_t O, int32_t softmax,
                     float *y, void *) {
   if (!x || !W || !y) return KVAE_ERR_NULL;
-  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (softmax && O > 16)) return KVAE_ERR_DIMS;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 12288 || (softmax && O > 16)) return KVAE_ERR_DIMS;
   for (int64_t n = 0; n < N; ++n) {
     float mx = -INFINITY;
     for (int o = 0; o < O; ++o) {
@@ -817,7 +818,7 @@ int kvae_linear_fwd(const float *x, int64_t xs, int64_t N, int32_t F, const floa
 int kvae_linear_bwd_input(const float *g, const float *y, int64_t N, int32_t F, const float *W, int32_t O, float *g_logit, float *dx,
                           int64_t dxs, void *) {
   if (!g || !W || !dx || (y && !g_logit)) return KVAE_ERR_NULL;
-  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 16384 || (y && O > 16)) return KVAE_ERR_DIMS;
+  if (N < 1 || F < 1 || F > 128 || O < 1 || (int64_t)O * F > 12288 || (y && O > 16)) return KVAE_ERR_DIMS;
   for (int64_t n = 0; n < N; ++n) {
     float gl[256], dot = 0.f;
     for (int o = 0; o < O && y; ++o) dot = std::fma(g[n * O + o], y[n * O + o], dot);

@@ -38,7 +38,7 @@ def vs_oracle_random(DEV, B, T, n, m, p, K, dense_q=False):
     from kvae.kalman.lgssm_ops import Slots
     slots = Slots(A=offs[0], B=offs[1], C=offs[2])
     ms, Ss, mf, Sf, mp, Sp = LgssmSmooth.apply(leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots, True)
-    total, terms = LgssmElbo.apply(ms, Ss, eps, leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots)
+    total, terms, levels_dev = LgssmElbo.apply(ms, Ss, eps, leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots)
     # values: C oracle
     c = lambda t: t.detach().cpu()
     ref = c_oracle.smooth(c(Y), c(U), c(mask), c(As), c(Bs), c(Cs), c(Q), c(R), c(mu0), c(S0))
@@ -100,7 +100,7 @@ def grads_vs_fp64_oracle(DEV, B, T, n, K):
     rec, offs, _ = mix_dynamics(leaves[3], leaves[:3])
     slots = Slots(A=offs[0], B=offs[1], C=offs[2])
     ms, Ss, *_ = LgssmSmooth.apply(leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots, True)
-    total, _ = LgssmElbo.apply(ms, Ss, eps, leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots)
+    total, _, levels_dev = LgssmElbo.apply(ms, Ss, eps, leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots)
     (total / (B * T)).backward()
     g64 = _torch_oracle_grads(problem, Q, R, mu0, S0, torch.float64)
     g32 = _torch_oracle_grads(problem, Q, R, mu0, S0, torch.float32)
@@ -236,12 +236,82 @@ def safe_cholesky_levels(DEV, n=4, B=2, T=4):
     for q00, want in ((0.02, 0), (-3e-6, 1), (-1.0, 5)):
         Q = (0.02 * torch.eye(n, device=DEV)).expand(B, T, n, n).contiguous()
         Q[1, 2, 0, 0] = q00
-        total, terms = LgssmElbo.apply(mus, Sig, eps, Y, U, mask, None, A[0], Bm[0], Cm[0], Q, R, mu0, S0, Slots())
+        total, terms, levels_dev = LgssmElbo.apply(mus, Sig, eps, Y, U, mask, None, A[0], Bm[0], Cm[0], Q, R, mu0, S0, Slots())
         rterms, levels = c_oracle.elbo_terms(c(mus), c(Sig), c(eps), c(Y), c(U), c(mask), c(A[0]), c(Bm[0]), c(Cm[0]), c(Q),
                                              c(R), c(mu0), c(S0))
         assert levels[1] == want, levels
+        assert levels_dev.cpu().tolist()[:2] == list(levels[:2])
+        if str(DEV).startswith("cuda"):   # which kernel family computed it: thread-per-step at n = 4, matrix cores at n = 16
+            assert int(levels_dev[2]) in {4: (0, 1), 16: (2,)}.get(n, (0,)), (n, int(levels_dev[2]))
         for i in range(4):
             assert abs(float(terms[i]) - rterms[i]) <= 3e-4 * abs(rterms[i]) + 1e-3, (i, float(terms[i]), rterms[i])
+
+
+def safe_cholesky_levels_shared_q(DEV, n=16, B=5, T=10):
+    """The same ladder with ONE Q for the whole batch (lstm dynamics: a broadcast [n,n] operand) - at n = 16 the four-steps-per-
+    wavefront kernels - and with the raised level coming from a smoothed covariance, so that the parked z_t have to be redone
+    at the resolved level: (level of Sigma_s, level of Q) in {(0,0), (0,1), (3,0), (5,0), (2,5)}; values and every gradient
+    against the C oracle / the torch oracle's autograd on the expanded stacks."""
+    from kvae.kalman.lgssm_ops import LgssmElbo, Slots
+    from oracle import c_oracle
+    from oracle import torch_oracle as O
+    m, p = n, 2
+    A, Bm, Cm, alpha, Y, U, mask, eps = _random_problem(B, T, n, m, p, 1, 7, DEV)
+    R = 0.03 * torch.eye(p, device=DEV)
+    mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)
+    gen = torch.Generator().manual_seed(2)
+    mus = torch.randn(B, T, n, generator=gen).to(DEV)
+    W = torch.randn(B, T, n, n, generator=gen) * 0.1
+    Sig0 = (W @ W.mT + 0.3 * torch.eye(n)).to(DEV)
+    c = lambda t: t.detach().cpu()
+    for sig_bad, q_bad, want in ((None, None, [0, 0]), (None, -3e-6, [0, 1]), (-4e-4, None, [3, 0]), (-1.0, None, [5, 0]),
+                                 (-5e-5, -1.0, [2, 5])):
+        Sig = Sig0.clone()
+        if sig_bad is not None:
+            Sig[B - 1, T - 3] = torch.diag(torch.tensor([sig_bad] + [0.2] * (n - 1))).to(DEV)
+        Q = 0.02 * torch.eye(n, device=DEV)
+        if q_bad is not None:
+            Q[2, 2] = q_bad
+        leaves = [t.clone().requires_grad_(True) for t in (mus, Sig, Y, A[0], Bm[0], Cm[0], Q)]
+        total, terms, levels_dev = LgssmElbo.apply(leaves[0], leaves[1], eps, leaves[2], U, mask, None, leaves[3], leaves[4], leaves[5],
+                                                   leaves[6], R, mu0, S0, Slots())
+        assert levels_dev.cpu().tolist()[:2] == want, (levels_dev.cpu().tolist(), want)
+        if str(DEV).startswith("cuda") and n == 16:
+            assert int(levels_dev[2]) == 2, int(levels_dev[2])   # gQ is wanted here: one step per wavefront
+        ex = lambda M: c(M).expand(B, T, *M.shape).contiguous()
+        rterms, levels = c_oracle.elbo_terms(c(mus), c(Sig), c(eps), c(Y), c(U), c(mask), c(A[0]), c(Bm[0]), c(Cm[0]), ex(Q),
+                                             c(R), c(mu0), c(S0))
+        assert list(levels[:2]) == want
+        for i in range(4):
+            assert abs(float(terms[i]) - rterms[i]) <= 3e-4 * abs(rterms[i]) + 1e-3, (want, i, float(terms[i]), rterms[i])
+        # gradients vs the torch oracle's autograd on the same problem
+        ref = [c(t).clone().requires_grad_(True) for t in (mus, Sig, Y, A[0], Bm[0], Cm[0], Q)]
+        e = lambda M: M.expand(B, T, *M.shape)
+        want_total = O.lgssm_elbo(ref[0].unsqueeze(-1), ref[1], ref[2], c(U), e(ref[3]), e(ref[4]), e(ref[5]), e(ref[6]), c(R), c(mu0),
+                                  c(S0), c(mask), c(eps)) * c(mask).sum().clamp(min=1.0)
+        assert rel_err(total.detach().cpu(), want_total.detach()) < 1e-4, want
+        total.backward()
+        want_total.backward()
+        for k, (got, r) in enumerate(zip(leaves, ref)):
+            if r.grad is None or float(r.grad.abs().max()) == 0.0:
+                assert got.grad is None or float(got.grad.abs().max()) < 1e-6, (want, k)
+            else:
+                assert rel_err(got.grad.cpu(), r.grad) < 3e-3, (want, k)
+        # without gradients of Q the shared-Q call takes the four-steps-per-wavefront kernels (family 3): same value
+        with torch.no_grad():
+            tot4, _, lv4 = LgssmElbo.apply(mus, Sig, eps, Y, U, mask, None, A[0], Bm[0], Cm[0], Q, R, mu0, S0, Slots())
+        assert lv4.cpu().tolist()[:2] == want and rel_err(tot4.cpu(), total.detach().cpu()) < 1e-5
+        if str(DEV).startswith("cuda") and n == 16:
+            assert int(lv4[2]) == 3, int(lv4[2])
+        # ... and with gradients w.r.t. everything but Q (the training step of the lstm model, whose Q is a buffer)
+        lv2 = [t.clone().requires_grad_(True) for t in (mus, Sig, Y, A[0], Bm[0], Cm[0])]
+        tot5, _, lv5 = LgssmElbo.apply(lv2[0], lv2[1], eps, lv2[2], U, mask, None, lv2[3], lv2[4], lv2[5], Q, R, mu0, S0, Slots())
+        tot5.backward()
+        if str(DEV).startswith("cuda") and n == 16:
+            assert int(lv5[2]) == 3, int(lv5[2])
+        for k, (got, r) in enumerate(zip(lv2, ref[:6])):
+            if r.grad is not None and float(r.grad.abs().max()) > 0.0:
+                assert rel_err(got.grad.cpu(), r.grad) < 3e-3, (want, k, "four-step")
 
 
 def jitter_golden(DEV, name, levels):
@@ -253,10 +323,14 @@ def jitter_golden(DEV, name, levels):
     g = load(name)
     d = {k: v.to(DEV) for k, v in g.items()}
     leaves = {k: d[k].clone().requires_grad_(True) for k in JITTER_GRADS}
-    total, _ = LgssmElbo.apply(leaves["mu_s"], leaves["Sig_s"], d["eps_z"], leaves["a"], d["u"], d["mask"], None,
+    total, _, levels_dev = LgssmElbo.apply(leaves["mu_s"], leaves["Sig_s"], d["eps_z"], leaves["a"], d["u"], d["mask"], None,
                                leaves["A_list"], leaves["B_list"], leaves["C_list"], leaves["Q_list"], d["R"], d["mu0"],
                                d["Sigma0"], Slots())
-    assert LgssmElbo.last_chol_levels.cpu().tolist() == levels
+    assert levels_dev.cpu().tolist()[:2] == levels
+    if str(DEV).startswith("cuda") and d["Sig_s"].shape[-1] == 16:
+        # the (16,16,2) matrix-core kernels computed this call at a RAISED level themselves (no generic backup launch):
+        # family 2 = one step per wavefront (a per-step Q_list)
+        assert int(levels_dev[2]) == 2, int(levels_dev[2])
     elbo = total / d["mask"].sum().clamp(min=1.0)
     assert rel_err(elbo.detach().cpu(), g["elbo"]) < 1e-4
     (-elbo).backward()

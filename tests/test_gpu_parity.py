@@ -161,6 +161,13 @@ def test_safe_cholesky_levels(n, B, T):
     parity_cases.safe_cholesky_levels(DEV, n, B, T)
 
 
+@pytest.mark.parametrize("n,B,T", [(16, 5, 10), (16, 33, 7), (4, 3, 6), (7, 2, 5)])
+def test_safe_cholesky_levels_shared_q(n, B, T):
+    """Raised levels and the diagonal fallback with a batch-wide Q, for Sigma_s and Q: at n = 16 on the matrix-core kernels of
+    BOTH layouts (the launch reports its family), no generic backup launch."""
+    parity_cases.safe_cholesky_levels_shared_q(DEV, n, B, T)
+
+
 @pytest.mark.parametrize("name,levels", JITTER_CASES)
 def test_jitter_golden_gpu(name, levels):
     """_safe_cholesky past level 0, pinned to the REFERENCE (fixtures driven through its own elbo)."""

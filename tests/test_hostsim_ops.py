@@ -149,6 +149,7 @@ def test_linearity_hostsim():
 def test_safe_cholesky_levels_hostsim():
     import parity_cases
     parity_cases.safe_cholesky_levels("cpu")
+    parity_cases.safe_cholesky_levels_shared_q("cpu", n=4, B=3, T=6)
 
 
 @pytest.mark.parametrize("name,levels", JITTER_CASES)

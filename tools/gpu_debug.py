@@ -31,7 +31,7 @@ for (n, m, p, tag) in ((3, 2, 1, "generic"), (4, 4, 2, "static")):
     c = lambda t: t.detach().cpu()
     ref = c_oracle.smooth(c(Y), c(U), c(mask), c(As), c(Bs), c(Cs), c(Q), c(R), c(mu0), c(S0))
     print("   mus_smooth rel", rel_err(c(outs[0]), ref["mus_smooth"]), "Sig_smooth rel", rel_err(c(outs[1]), ref["Sigmas_smooth"]), flush=True)
-    total, terms = stage(f"elbo_{tag}", lambda: LgssmElbo.apply(outs[0], outs[1], eps, leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots))
+    total, terms, _lv = stage(f"elbo_{tag}", lambda: LgssmElbo.apply(outs[0], outs[1], eps, leaves[4], leaves[5], mask, rec, None, None, None, Q, R, mu0, S0, slots))
     rt, lv = c_oracle.elbo_terms(c(outs[0]), c(outs[1]), c(eps), c(Y), c(U), c(mask), c(As), c(Bs), c(Cs), c(Q), c(R), c(mu0), c(S0))
     print("   terms", terms.tolist(), "oracle", rt.tolist(), flush=True)
     stage(f"backward_{tag}", lambda: total.backward())

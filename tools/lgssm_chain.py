@@ -50,7 +50,7 @@ def chain():
         rec, offs, _ = mix_dynamics(alpha, [A, Bm, Cm])
         slots, Cop, Qop = Slots(A=offs[0], B=offs[1], C=offs[2]), None, Q
     ms, Ss, *_ = LgssmSmooth.apply(Y, U, None, rec, None, None, Cop, Qop, R, mu0, S0, slots, True)
-    total, _ = LgssmElbo.apply(ms, Ss, eps, Y, U, None, rec, None, None, Cop, Qop, R, mu0, S0, slots)
+    total, _, levels_dev = LgssmElbo.apply(ms, Ss, eps, Y, U, None, rec, None, None, Cop, Qop, R, mu0, S0, slots)
     (total / (B * T) + 1e-3 * h.sum()).backward()
 
 

@@ -80,7 +80,7 @@ _native.profile_start()
 for _ in range(a.iters):
     rec, slots, Cop, Qop, views = operands()
     ms, Ss, mf, Sf, mp, Sp = LgssmSmooth.apply(Y, U, mask, rec, None, None, Cop, Qop, R, mu0, S0, slots, True)
-    total, _ = LgssmElbo.apply(ms, Ss, eps, Y, U, mask, rec, None, None, Cop, Qop, R, mu0, S0, slots)
+    total, _, levels_dev = LgssmElbo.apply(ms, Ss, eps, Y, U, mask, rec, None, None, Cop, Qop, R, mu0, S0, slots)
     (total / (B * T)).backward()
 prof = _native.profile_stop()
 us = {k: 1e3 * sorted(v)[len(v) // 2] for k, v in prof.items()}
