@@ -71,7 +71,12 @@ KV_DEV int probe_level(float *Lo, float *sym, const float *X, int n) {
 #if defined(KVAE_HOSTSIM)
 KV_DEV void atomic_max_i32(int32_t *p, int32_t v) { if (v > *p) *p = v; }
 #else
-KV_DEV void atomic_max_i32(int32_t *p, int32_t v) { atomicMax(p, v); }
+// (a plain read first: when the whole batch needs a raised level, a hundred thousand wavefronts would otherwise queue on one
+// address - 2.3 ms of atomics at the configs[4] shard - while all but the first few find their level already recorded)
+KV_DEV void atomic_max_i32(int32_t *p, int32_t v) {
+  if (*reinterpret_cast<volatile int32_t *>(p) >= v) return;
+  atomicMax(p, v);
+}
 #endif
 
 // ws (optional) receives per (b,t) the sample z_t = mu_t + L_t eps_t (n floats) of level 0: when the whole batch resolves to
