@@ -95,8 +95,9 @@ int kvae_lgssm_filter_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
  * KalmanFilter.smooth (kalman_filter.py:204-237, 249-272). Reads filt/pred, writes smooth. */
 int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *io, void *stream);
 
-/* Filter + RTS in ONE launch (one wavefront per sequence, whole T loop in-kernel):
- * replaces KalmanFilter.smooth (kalman_filter.py:240-279). Writes all six stacks. */
+/* Filter + RTS in ONE launch, the whole T loop in-kernel: sixteen sequences per wavefront at (n,m,p) = (4,4,2), one sequence per
+ * wavefront on the f32 matrix cores at (16,16,2) and in the run-time-dimension kernels otherwise.
+ * Replaces KalmanFilter.smooth (kalman_filter.py:240-279). Writes all six stacks. */
 int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream);
 
 /* Kalman filter with the LSTM alpha-network stepped INSIDE the kernel (masked sequences: the network input of a

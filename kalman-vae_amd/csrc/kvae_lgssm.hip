@@ -238,9 +238,6 @@ static bool n16_ok(const kvae_lgssm_problem *p) {
   return env && p->n == 16 && p->m == 16 && p->p == 2 && stack16(p->A) && stack16(p->Bm) && stack16(p->C) && stack16(p->Q) &&
          aligned16(p->mu0) && p->mu0_sb % 4 == 0 && aligned16(p->Sigma0) && p->Sigma0_sb % 4 == 0 && aligned16(p->U);
 }
-extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
-                                     const kvae_lgssm_input_grads *out, float *ws, int with_rts, hipStream_t s);
-
 extern "C" int kvae_wide_launch_filter_alpha_lstm(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, const float *w_ih,
                                                   const float *w_hh, const float *b_ih, const float *b_hh, const float *head_w,
                                                   const float *head_b, const float *A, const float *Bm, const float *C, int K,
@@ -367,10 +364,6 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
       kvae_n16_launch_bwd(prob, saved, up, out, ws, fp == 4, s);
       return launch_status("k_smooth_bwd_n16");
     }
-  }
-  if (prob->n > 8 && getenv("KVAE_WIDE_BWD")) {   // measured slower than one wavefront at n = 16 (17.9 vs 15.6 ms at the C5
-    kvae_wide_launch_bwd(prob, saved, up, out, ws, with_rts, s);   // shard): the backward is bound by its serial solves; opt-in only
-    return launch_status("k_smooth_bwd_wide");
   }
   KVAE_DISPATCH(*prob, k_smooth_bwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *saved, *up, *out, ws,
                                            with_rts));
@@ -1145,11 +1138,8 @@ int kvae_dec_up_fwd(const float *x, const float *W, const float *bias, float *ou
   if (dec_up_wino()) {   // pairs of workgroups (one per half of the output channels) walk the column sets together
     const int64_t sets = side == 8 ? N : (N + 3) / 4;
     const dim3 wgrid((unsigned)(sets < dec_up_cap() ? sets : dec_up_cap()));
-    static const int pm = getenv("KVAE_WINO_PM") ? atoi(getenv("KVAE_WINO_PM")) : 1;   // 0: k-step-major MFMA order (A/B runs)
-    if (side == 8 && pm) k_dec_up_fwd_wino<8, true><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
-    else if (side == 8) k_dec_up_fwd_wino<8, false><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
-    else if (pm) k_dec_up_fwd_wino<4, true><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
-    else k_dec_up_fwd_wino<4, false><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    if (side == 8) k_dec_up_fwd_wino<8><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
+    else k_dec_up_fwd_wino<4><<<wgrid, dim3(512), 0, (hipStream_t)stream>>>(x, W, bias, out, N);
     return launch_status("k_dec_up_fwd_wino");
   }
   if (side == 8) k_dec_up_fwd<8><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, W, bias, out, N);

@@ -97,8 +97,7 @@ __global__ __launch_bounds__(64) void k_elbo_zfix_n16(kvae_lgssm_problem P, cons
   n16::elbo_zfix(P, Sig_s, mus, eps, zst, levels, b, t0);
 }
 static bool elbo_shared_q(const kvae_lgssm_problem *p) {
-  static const int env = getenv("KVAE_ELBO4") ? atoi(getenv("KVAE_ELBO4")) : 1;   // 0: one step per wavefront (A/B runs)
-  return env != 0 && p->Q.sb == 0 && p->Q.st == 0;
+  return p->Q.sb == 0 && p->Q.st == 0;
 }
 
 extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,

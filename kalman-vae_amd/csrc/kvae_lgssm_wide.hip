@@ -25,20 +25,6 @@ __global__ __launch_bounds__(256) void k_smooth_fwd_wide(kvae_lgssm_problem P, k
   if (do_rts) rts_sweep(d, P, S, b, L);
 }
 
-template <class D>
-__global__ __launch_bounds__(256) void k_smooth_bwd_wide(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
-                                                         kvae_lgssm_input_grads G, float *ws, int with_rts) {
-  __shared__ BwdLds<D> L;
-  const D d(P.n, P.m, P.p);
-  const int b = blockIdx.x;
-  if (with_rts)
-    rts_bwd_sweep(d, P, S, U, G, ws, b, L);
-  else
-    filter_bwd_seed(d, P, U, G, ws, b);
-  KV_SYNC();
-  filter_bwd_sweep(d, P, S, G, ws, b, L);
-}
-
 // launchers used by kvae_lgssm.hip (not part of the public C ABI)
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s) {
@@ -46,13 +32,6 @@ extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgs
     k_smooth_fwd_wide<SDims<16, 16, 2>><<<dim3(p->B), dim3(256), 0, s>>>(*p, *st, do_filter, do_rts);
   else
     k_smooth_fwd_wide<RDims><<<dim3(p->B), dim3(256), 0, s>>>(*p, *st, do_filter, do_rts);
-}
-extern "C" void kvae_wide_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
-                                     const kvae_lgssm_input_grads *out, float *ws, int with_rts, hipStream_t s) {
-  if (p->n == 16 && p->m == 16 && p->p == 2)
-    k_smooth_bwd_wide<SDims<16, 16, 2>><<<dim3(p->B), dim3(256), 0, s>>>(*p, *saved, *up, *out, ws, with_rts);
-  else
-    k_smooth_bwd_wide<RDims><<<dim3(p->B), dim3(256), 0, s>>>(*p, *saved, *up, *out, ws, with_rts);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -116,7 +116,7 @@ struct WinoFwd {
   static constexpr int VROW = 20, VSET = 8 * 64 * VROW;
 };
 
-template <int S, bool PM>
+template <int S>
 __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict__ x, const float *__restrict__ W,
                                                          const float *__restrict__ bias, float *__restrict__ out, int64_t N) {
   using D = UpDims<S>;
@@ -187,64 +187,6 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
         *reinterpret_cast<float4 *>(vw + vbase_w + h * 64 * K::VROW + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
   };
-  auto compute_k = [&](const float *vr, int64_t k) {     // 128 MFMAs + output transform, bias, shuffle, ReLU of column set k
-    wn_f4 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) acc[p] = wn_f4{0.f, 0.f, 0.f, 0.f};
-    // B operands one k-step ahead, PINNED there: hipcc otherwise sinks each ds_read_b128 to just before its MFMA and the LDS
-    // latency (the helpers' transform traffic included) sits in the MFMA stream twice per k-step (stamps: 70 cycles / MFMA)
-    float4 b[4], bn[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4 *>(vr + vbase_r + 4 * q);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s + 1 < 8) {
-#ifdef WN_DIAG_NOLDS
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bn[q] = make_float4(b[q].y, b[q].z, b[q].w, b[q].x);
-#else
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bn[q] = *reinterpret_cast<const float4 *>(vr + vbase_r + (s + 1) * 64 * K::VROW + 4 * q);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[4 * q + 0] = WN_MFMA(U[4 * q + 0][s], b[q].x, acc[4 * q + 0]);
-        acc[4 * q + 1] = WN_MFMA(U[4 * q + 1][s], b[q].y, acc[4 * q + 1]);
-        acc[4 * q + 2] = WN_MFMA(U[4 * q + 2][s], b[q].z, acc[4 * q + 2]);
-        acc[4 * q + 3] = WN_MFMA(U[4 * q + 3][s], b[q].w, acc[4 * q + 3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = bn[q];
-    }
-    // register r = sub-pixel (dy, dx) = (r >> 1, r & 1) of shuffle channel co0 / 4 + g
-    const uint32_t o0 = (uint32_t)(k * Wd::FPC * D::YFRAME + obase);
-    float y[4][4];                                   // [r][2a + b]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float m[16];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) m[p] = acc[p][r];
-      wino_out(m, y[r]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[r][q] = fmaxf(y[r][q] + bv[r], 0.f);
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {               // image row 4 ty + 2a + dy: columns (b, dx) = (0,0) (0,1) (1,0) (1,1)
-        const float4 row = make_float4(y[2 * dy][2 * a], y[2 * dy + 1][2 * a], y[2 * dy][2 * a + 1], y[2 * dy + 1][2 * a + 1]);
-        em_st4(ry, (o0 + (uint32_t)((2 * a + dy) * 2 * S)) * 4u, row);
-      }
-  };
-
-  // 128 MFMAs + output transform, bias, shuffle, ReLU of column set k.  POINT-major: the eight k-steps of a pair of points run
-  // back to back on two accumulators (alternating: the 40-cycle dependent latency of the 16x16x4 MFMA is covered), and a finished
-  // pair is folded into the 16 outputs (A^T . A is linear: y += its share) while the next pair is on the matrix core.  Eight live
-  // accumulator registers instead of 64, and the wave's vector work is spread under its own MFMAs instead of following them in
-  // a block that the partner wave of the SIMD can only partly cover (k-step-major: 11.3 k cycles per column set, stamps).
   auto compute_p = [&](const float *vr, int64_t k) {
     float y[4][4];                                   // [r][2a + b]
 #pragma unroll
@@ -306,7 +248,7 @@ __global__ __launch_bounds__(512) void k_dec_up_fwd_wino(const float *__restrict
       }
   };
 
-#define WN_COMPUTE(vr, k) do { if constexpr (PM) compute_p((vr), (k)); else compute_k((vr), (k)); } while (0)
+#define WN_COMPUTE(vr, k) compute_p((vr), (k))
 
   // pipeline: at step n, xin[(n+1)&1] holds set n+1, vt[n&1] the transformed set n, pre the frames of set n+2
   int64_t k = blockIdx.x;

@@ -42,6 +42,9 @@ def vs_oracle_random(DEV, B, T, n, m, p, K, dense_q=False):
     # values: C oracle
     c = lambda t: t.detach().cpu()
     ref = c_oracle.smooth(c(Y), c(U), c(mask), c(As), c(Bs), c(Cs), c(Q), c(R), c(mu0), c(S0))
+    # n = 16: two float32 implementations of a 200-step recursion with different summation orders (matrix cores vs scalar
+    # loops) can sit 1e-3 apart while both are equally close to the truth; this first bar only catches gross errors there, the
+    # real one follows below - against a FLOAT64 run, within max(1e-4, 2 x the float32 oracle's own distance from it).
     tol = 2e-4 if n < 16 else 2e-3
     for k, v in (("mus_smooth", ms), ("Sigmas_smooth", Ss), ("mus_filt", mf), ("Sigmas_filt", Sf), ("mus_pred", mp),
                  ("Sigmas_pred", Sp)):
@@ -55,13 +58,21 @@ def vs_oracle_random(DEV, B, T, n, m, p, K, dense_q=False):
         return  # gradients up to configs[1] size (256,50,4) and (8,200,16); beyond, the torch-oracle tape takes minutes
     # gradients: autograd over the torch oracle
     (total / (B * T)).backward()
-    want = _torch_oracle_grads((A, Bm, Cm, alpha, Y, U, mask, eps), Q, R, mu0, S0, torch.float32)
+    v32 = {}
+    want = _torch_oracle_grads((A, Bm, Cm, alpha, Y, U, mask, eps), Q, R, mu0, S0, torch.float32, values=v32)
     for name, got, ref_g in zip("A B C alpha Y U".split(), leaves, want):
         assert rel_err(got.grad.cpu(), ref_g) < 3e-3, name
+    if n >= 16:   # the value bar where float32 is the limit (see above)
+        v64 = {}
+        _torch_oracle_grads((A, Bm, Cm, alpha, Y, U, mask, eps), Q, R, mu0, S0, torch.float64, values=v64)
+        for k, got in (("mus_smooth", ms), ("Sigmas_smooth", Ss), ("elbo_sum", total)):
+            tape, mine = rel_err(v32[k].double(), v64[k]), rel_err(c(got).double(), v64[k])
+            assert mine < max(1e-4, 2.0 * tape), (k, mine, tape)
 
 
-def _torch_oracle_grads(problem, Q, R, mu0, S0, dtype):
-    """d(ELBO / (B T)) / d(A, B, C, alpha, Y, U) by autograd over oracle/torch_oracle.py, computed in `dtype` on the CPU."""
+def _torch_oracle_grads(problem, Q, R, mu0, S0, dtype, values=None):
+    """d(ELBO / (B T)) / d(A, B, C, alpha, Y, U) by autograd over oracle/torch_oracle.py, computed in `dtype` on the CPU.
+    values: a dict that receives the forward results (mus_smooth [B,T,n], Sigmas_smooth, elbo_sum)."""
     from oracle import torch_oracle as O
     c = lambda t: t.detach().cpu().to(dtype)
     A, Bm, Cm, alpha, Y, U, mask, eps = problem
@@ -82,8 +93,65 @@ def _torch_oracle_grads(problem, Q, R, mu0, S0, dtype):
         mus.insert(0, m_s), Sigs.insert(0, S_s)
     tr, em, ini, ent = O.lgssm_elbo_terms(torch.stack(mus, 1), torch.stack(Sigs, 1), cl[4], cl[5], Ar, Br, Cr, c(Q), c(R),
                                           c(mu0), c(S0), c(mask), c(eps))
+    if values is not None:
+        values.update(mus_smooth=torch.stack(mus, 1).detach().squeeze(-1), Sigmas_smooth=torch.stack(Sigs, 1).detach(),
+                      elbo_sum=(tr + em + ini + ent).detach())
     ((tr + em + ini + ent) / (B * T)).backward()
     return [t.grad for t in cl]
+
+
+def values_vs_fp64_oracle(DEV, B, T, n, K):
+    """north_star asks for ELBO and smoothed means within 1e-4 of the reference's CPU path.  At n = 16 over T = 200 float32 itself
+    cannot promise that (the reference's own float32 run of stress_switch_z16_B2_T200 is 3.4e-4 from a float64 run of the same
+    recursion), so here the float64 oracle is the truth and the bar is written as an assertion instead of a flat 2e-3: the HIP
+    smoothed means, smoothed covariances and ELBO must lie within max(1e-4, 2 x the float32 oracle's own distance) of it."""
+    from kvae.kalman.lgssm_ops import LgssmElbo, LgssmSmooth, Slots, mix_dynamics
+    problem = _random_problem(B, T, n, n, 2, K, 100 + B + T, DEV)
+    A, Bm, Cm, alpha, Y, U, mask, eps = problem
+    R, Q = 0.03 * torch.eye(2, device=DEV), 0.02 * torch.eye(n, device=DEV)
+    mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)
+    with torch.no_grad():
+        rec, offs, _ = mix_dynamics(alpha, [A, Bm, Cm])
+        slots = Slots(A=offs[0], B=offs[1], C=offs[2])
+        ms, Ss, *_ = LgssmSmooth.apply(Y, U, mask, rec, None, None, None, Q, R, mu0, S0, slots, True)
+        total, _, _ = LgssmElbo.apply(ms, Ss, eps, Y, U, mask, rec, None, None, None, Q, R, mu0, S0, slots)
+    v64, v32 = {}, {}
+    _torch_oracle_grads(problem, Q, R, mu0, S0, torch.float64, values=v64)
+    _torch_oracle_grads(problem, Q, R, mu0, S0, torch.float32, values=v32)
+    report = {}
+    for k, got in (("mus_smooth", ms), ("Sigmas_smooth", Ss), ("elbo_sum", total)):
+        tape = rel_err(v32[k].double(), v64[k])
+        mine = rel_err(got.cpu().double(), v64[k])
+        report[k] = (mine, tape)
+        assert mine < max(1e-4, 2.0 * tape), (k, mine, tape)
+    return report
+
+
+_FP64_CACHE = {}
+
+
+def latent_fp64_budget(g, kind, name):
+    """Float64 and float32 runs of the torch oracle on a latent golden's inputs: (outputs of the float64 run, per-key distance of
+    the float32 run from it).  The fixture itself is a float32 run of the REFERENCE, so it sits at the same distance."""
+    if name in _FP64_CACHE:
+        return _FP64_CACHE[name]
+    from golden_util import sub
+    from oracle import torch_oracle as O
+
+    def run(dt):
+        c = lambda t: t.to(dt) if t.is_floating_point() else t
+        dyn = {k: c(v) for k, v in sub(g, "dyn.").items()}
+        kw = {}
+        if kind == "switching":
+            kw = dict(tau=float(g["tau"]), is_training=bool(g["train"]), gumbel=c(g["gumbel"]), trans_matrix=c(g["trans_matrix"]))
+        with torch.no_grad():
+            return O.smooth_and_elbo(dyn, kind, c(g["a"]), c(g["u"]), c(g["mask"]), c(g["Qbuf"]), c(g["R"]), c(g["mu0"]),
+                                     c(g["Sigma0"]), c(g["eps_z"]), **kw)
+
+    o64, o32 = run(torch.float64), run(torch.float32)
+    dist = {k: rel_err(o32[k].double(), o64[k]) for k in o64 if torch.is_tensor(o64[k]) and o64[k].is_floating_point()}
+    _FP64_CACHE[name] = (o64, dist)
+    return o64, dist
 
 
 def grads_vs_fp64_oracle(DEV, B, T, n, K):
@@ -715,3 +783,37 @@ def small_linear_vs_torch(DEV):
         gx = base_dev.grad[:, 0] if strided else x_dev.grad
         assert rel_err(gx.cpu(), x_ref.grad) < 2e-5
         assert rel_err(w_dev.grad.cpu(), w_ref.grad) < 2e-5 and rel_err(b_dev.grad.cpu(), b_ref.grad) < 2e-5
+
+
+def backward_shard_vs_slices(DEV, B, T, n, slice_b):
+    """The LGSSM forward + ELBO + backward on B sequences in one launch against the same on B / slice_b launches of slice_b
+    sequences each: per-sequence gradients (Y, U, alpha) bit-identical; the summed base-matrix gradients (A, B, C: reduced over
+    the batch in a different grouping) to rounding.  Runs under no host-side oracle: the slices ARE the oracle-checked size."""
+    from kvae.kalman.lgssm_ops import LgssmElbo, LgssmSmooth, Slots, mix_dynamics
+    A, Bm, Cm, alpha, Y, U, mask, eps = _random_problem(B, T, n, n, 2, 3, 100 + B + T, DEV)
+    R, Q = 0.03 * torch.eye(2, device=DEV), 0.02 * torch.eye(n, device=DEV)
+    mu0, S0 = torch.zeros(n, device=DEV), 20.0 * torch.eye(n, device=DEV)
+
+    def run(sl):
+        leaves = [t.clone().requires_grad_(True) for t in (A, Bm, Cm, alpha[sl], Y[sl], U[sl])]
+        rec, offs, _ = mix_dynamics(leaves[3], leaves[:3])
+        slots = Slots(A=offs[0], B=offs[1], C=offs[2])
+        mk = None if mask is None else mask[sl]
+        ms, Ss, *_ = LgssmSmooth.apply(leaves[4], leaves[5], mk, rec, None, None, None, Q, R, mu0, S0, slots, True)
+        total, _, _ = LgssmElbo.apply(ms, Ss, eps[sl], leaves[4], leaves[5], mk, rec, None, None, None, Q, R, mu0, S0, slots)
+        total.backward()
+        return [t.grad for t in leaves], rec.detach(), ms.detach()
+
+    big, rec_big, ms_big = run(slice(0, B))
+    assert all(torch.isfinite(g).all() for g in big)
+    acc = [torch.zeros_like(g) for g in big[:3]]
+    for b0 in range(0, B, slice_b):
+        sl = slice(b0, b0 + slice_b)
+        small, _, ms_small = run(sl)
+        assert torch.equal(ms_small, ms_big[sl])
+        for k, name in ((3, "alpha"), (4, "Y"), (5, "U")):
+            assert torch.equal(small[k], big[k][sl]), (name, b0)
+        for k in range(3):
+            acc[k] += small[k]
+    for k, name in enumerate("ABC"):
+        assert rel_err(acc[k].cpu(), big[k].cpu()) < 1e-4, name

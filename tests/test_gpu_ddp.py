@@ -79,11 +79,13 @@ def _rccl_worker(port, q):
     g = torch.Generator().manual_seed(5)
     nz = dict(eps_a=torch.randn(16 * 12, 2, generator=g).cuda(), eps_z=torch.randn(16, 12, 4, generator=g).cuda())
     res = []
-    for world_arg in (2, 1):          # 2: graph cut around the (one-rank) RCCL all-reduce; 1: the single-graph step
+    # (2, False): graph cut around the (one-rank) eager RCCL all-reduce; (2, True): the RCCL call captured INTO the step graph -
+    # one replay per step; (1, False): the single-graph single-rank step
+    for world_arg, in_graph in ((2, False), (2, True), (1, False)):
         torch.manual_seed(0)
         model = KVAE(KVAEConfig(dynamics_model="lstm", num_modes=3)).cuda().train()
         model.beta = 1.0
-        tr = Trainer(model, use_graph=True, world_size=world_arg)
+        tr = Trainer(model, use_graph=True, world_size=world_arg, graph_allreduce=in_graph)
         with noise.inject(**nz):
             for _ in range(4):
                 out = tr.step(x)
@@ -108,11 +110,12 @@ def test_split_graph_with_a_real_rccl_communicator():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(port, q))
     p.start()
-    (p2, l2, split2), (p1, l1, split1) = q.get(timeout=600)
+    (p2, l2, split2), (pg, lg, splitg), (p1, l1, split1) = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
-    assert split2 and not split1
+    assert split2 and not split1 and not splitg       # graph_allreduce: ONE graph holds forward, backward, all-reduce, clip, Adam
     assert np.isfinite(l2) and abs(l2 - l1) <= 1e-4 * abs(l1)
+    assert abs(lg - l2) <= 1e-6 * abs(l2) and float(np.abs(pg - p2).max()) < 1e-6   # same arithmetic as the cut graph
     # the multi-rank path scales the flat gradient by the frame count and divides it out again after the all-reduce: last-bit
     # differences, which four Adam steps of lr 7e-3 can turn into a few 1e-4 on parameters whose gradient is nearly zero
     assert float(np.abs(p2 - p1).max()) < 2e-3

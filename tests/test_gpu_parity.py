@@ -31,7 +31,7 @@ def test_latent_gpu(name, kind):
     g = load(name)
     kf = make_filter(g, kind, DEV)
     a, outs, elbo = run_latent(kf, g, DEV)
-    check_latent(kf, g, a, outs, elbo, name, tol_scale=2.0)
+    check_latent(kf, g, a, outs, elbo, name, tol_scale=2.0, kind=kind)
 
 
 @pytest.mark.parametrize("batch", [1, 4])
@@ -130,6 +130,21 @@ def test_single_mode_n16_vs_fp64_oracle(B, T, K):
     tape = parity_cases.grads_vs_fp64_oracle(DEV, B, T, 16, K)
     if K == 3:
         assert tape < 3e-3
+
+
+@pytest.mark.parametrize("B,T,K", [(8, 200, 3), (3, 37, 1)])
+def test_values_n16_vs_fp64_oracle(B, T, K):
+    """Smoothed means / covariances / ELBO at n = 16 within max(1e-4, 2 x the float32 oracle's own distance from float64) of the
+    float64 oracle: north_star's 1e-4 wherever float32 can deliver it, and an explicit, measured budget where it cannot."""
+    report = parity_cases.values_vs_fp64_oracle(DEV, B, T, 16, K)
+    assert all(mine < 2e-3 for mine, _ in report.values()), report
+
+
+def test_backward_at_the_full_shard_equals_its_slices():
+    """k_smooth_bwd_n16 at the full configs[4] shard (512, 200, 16) against the same kernel on 64 independent 8-sequence slices
+    (the size gradient parity with the torch oracle is checked at): sequences do not interact, so every gradient of the big
+    launch must be BIT-identical to the slice launches' - a wavefront-indexing or hand-off-record bug at 512 wavefronts shows here."""
+    parity_cases.backward_shard_vs_slices(DEV, 512, 200, 16, 8)
 
 
 def test_dec_up_workgroup_cap():
@@ -399,11 +414,11 @@ def test_explicit_ones_mask_equals_no_mask():
             assert rel_err(y.cpu(), x.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("env", [{"KVAE_WINO": "0"}, {"KVAE_WINO_PM": "0"}, {"KVAE_ELBO4": "0"}, {"KVAE_Q4": "0"}])
+@pytest.mark.parametrize("env", [{"KVAE_WINO": "0"}, {"KVAE_Q4": "0"}, {"KVAE_N16": "0"}])
 def test_ab_switches_select_working_kernels(env):
-    """The A/B switches read once per process (direct instead of Winograd decoder blocks, k-step-major Winograd forward, one
-    step per wavefront in the n = 16 ELBO, one wavefront per sequence at n = 4) must select kernels that still pass parity: a
-    fresh process per switch."""
+    """The fault-isolation switches that remain (read once per process: direct instead of Winograd decoder blocks, one wavefront
+    per sequence at n = 4, run-time-dimension kernels at n = 16 - each also the product's path for operands the specialised
+    kernels cannot take) must select kernels that still pass parity: a fresh process per switch."""
     import os
     import subprocess
     import sys

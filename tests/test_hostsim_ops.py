@@ -52,10 +52,22 @@ def run_latent(kf, g, device="cpu"):
     return a, outs, elbo
 
 
-def check_latent(kf, g, a, outs, elbo, name, tol_scale=1.0):
+def check_latent(kf, g, a, outs, elbo, name, tol_scale=1.0, kind=None):
     tol = (5e-5 if "z16" in name else 1e-5) * tol_scale
     if name == "stress_switch_z16_B2_T200":
-        tol = 2e-3  # fp32 error budget of this case, see tests/test_oracle_golden.py
+        # n = 16 over T = 200 with an unstable A: float32 itself is the limit (the reference's own float32 fixture is 3.4e-4 from
+        # a float64 run of the recursion).  The bar, as an assertion: within max(1e-4, 2 x the float32 oracle's own distance) of
+        # the FLOAT64 oracle, per output - not a flat 2e-3 against the float32 fixture.
+        import parity_cases
+        o64, dist = parity_cases.latent_fp64_budget(g, kind or "switching", name)
+        for k, v in zip(SMOOTH_KEYS, outs):
+            if k in ("A_list", "B_list", "C_list"):
+                continue
+            want = o64[k].squeeze(-1) if k.startswith("mus") else o64[k]
+            assert rel_err(v.detach().cpu().double().reshape(want.shape), want) < max(1e-4, 2.0 * dist[k]), (k, dist[k])
+        assert rel_err(elbo.detach().cpu().double(), o64["elbo"]) < max(1e-4, 2.0 * dist["elbo"]), ("elbo", dist["elbo"])
+        assert rel_err(kf.dyn_params.state_seq.cpu(), g["state_seq"]) < 1e-5
+        return
     for k, v in zip(SMOOTH_KEYS, outs):
         if k in g:
             assert rel_err(v.cpu(), g[k]) < tol, k
@@ -86,7 +98,7 @@ def test_latent_hostsim(name, kind):
     g = load(name)
     kf = make_filter(g, kind)
     a, outs, elbo = run_latent(kf, g)
-    check_latent(kf, g, a, outs, elbo, name)
+    check_latent(kf, g, a, outs, elbo, name, kind=kind)
 
 
 @pytest.mark.parametrize("batch", [1, 4])

@@ -33,10 +33,20 @@ def test_latent(name, kind):
                             g["eps_z"], **kw)
     tol = 5e-5 if "z16" in name else 1e-5
     if name == "stress_switch_z16_B2_T200":
-        # error budget: the reference's own fp32 result is 3.5e-4 (means) away from an fp64 run of the
-        # same recursion (unstable A = I + 0.05*randn at n=16 over T=200 amplifies rounding), so fp32
-        # implementations can only agree to that order here.
-        tol = 2e-3
+        # error budget: the reference's own fp32 result is 3.4e-4 (means) away from an fp64 run of the same recursion (unstable
+        # A = I + 0.05*randn at n=16 over T=200 amplifies rounding), so two fp32 implementations can only agree to twice that
+        # order here.  Measured, not assumed: the fixture (the REFERENCE's fp32 run) and the oracle's fp32 run must each lie
+        # within max(1e-4, 2 x that distance) of the oracle's fp64 run.
+        import parity_cases
+        o64, dist = parity_cases.latent_fp64_budget(g, kind, name)
+        for k in ("mus_smooth", "mus_filt", "mus_pred", "elbo"):
+            bar = max(1e-4, 2.0 * dist[k])
+            assert rel_err(g[k].double(), o64[k]) < bar and rel_err(out[k].detach().double(), o64[k]) < bar, (k, dist[k])
+        for k in ("Sigmas_smooth", "Sigmas_filt", "Sigmas_pred"):
+            bar = max(1e-4, 2.0 * dist[k])
+            assert rel_err(g[k + "_every8"].double(), o64[k][:, ::8]) < bar and rel_err(out[k].detach().double(), o64[k]) < bar, k
+        assert dist["mus_smooth"] < 1e-3   # the budget itself is part of the record
+        return
     for k in SMOOTH_KEYS + ["state_seq"]:
         if k in g:
             assert rel_err(out[k], g[k]) < tol, k
