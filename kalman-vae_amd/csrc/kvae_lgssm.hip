@@ -206,6 +206,13 @@ extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init
                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
                                           float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
                                           hipStream_t s);
+extern "C" int kvae_grid_launch_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                                           float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau,
+                                           const float *tau_dev, int hard, hipStream_t s);
+extern "C" int kvae_grid_launch_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
+                                           float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
+                                           hipStream_t s);
 extern "C" void kvae_wide_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                      hipStream_t s);
 // kvae_lgssm_n16.hip: (n, m, p) = (16, 16, 2) on the f32 matrix cores
@@ -902,7 +909,12 @@ int kvae_regime_fwd(const float *logits, const float *init_logits, const float *
                     void *stream) {
   if (!logits || !init_logits || !gumbel || !P || !y_seq || !log_q || !log_p) return KVAE_ERR_NULL;
   if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || (!tau_dev && !(tau > 0.f))) return KVAE_ERR_ARG;
-  static const int tpp_env = getenv("KVAE_REGIME_TPP") ? atoi(getenv("KVAE_REGIME_TPP")) : 1;   // 0: wave-per-sequence (A/B runs)
+  // 1 (default): lane-grid wavefront per sequence up to 4096 sequences of K <= 8, thread-per-sequence beyond; 2: thread-per-
+  // sequence always; 0: the LDS wave-per-sequence bodies of regime.h (any K <= 16: also the fallback of the other two)
+  static const int tpp_env = getenv("KVAE_REGIME_TPP") ? atoi(getenv("KVAE_REGIME_TPP")) : 1;
+  if (tpp_env == 1 && kvae_grid_launch_regime_fwd(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, K, tau, tau_dev, hard,
+                                                  (hipStream_t)stream))
+    return launch_status("k_regime_fwd_grid");
   if (tpp_env && kvae_tpp_launch_regime_fwd(logits, init_logits, gumbel, P, y_seq, log_q, log_p, B, T, K, tau, tau_dev, hard,
                                             (hipStream_t)stream))
     return launch_status("k_regime_fwd_tpp");
@@ -917,6 +929,9 @@ int kvae_regime_bwd(const float *logits, const float *init_logits, const float *
     return KVAE_ERR_NULL;
   if (B < 1 || T < 1 || K < 1 || K > KVAE_REGIME_MAX_K || (!tau_dev && !(tau > 0.f))) return KVAE_ERR_ARG;
   static const int tpp_env = getenv("KVAE_REGIME_TPP") ? atoi(getenv("KVAE_REGIME_TPP")) : 1;
+  if (tpp_env == 1 && kvae_grid_launch_regime_bwd(logits, init_logits, gumbel, P, y_seq, g_y, g_log_q, g_log_p, g_logits, g_init, B, T, K,
+                                                  tau, tau_dev, (hipStream_t)stream))
+    return launch_status("k_regime_bwd_grid");
   if (tpp_env && kvae_tpp_launch_regime_bwd(logits, init_logits, gumbel, P, y_seq, g_y, g_log_q, g_log_p, g_logits, g_init, B, T, K, tau,
                                             tau_dev, (hipStream_t)stream))
     return launch_status("k_regime_bwd_tpp");

@@ -103,3 +103,41 @@ extern "C" int kvae_tpp_launch_regime_bwd(const float *logits, const float *init
     default: return 0;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Regime chain, one wavefront per sequence as an 8 x 8 lane grid (regime_grid.h): K <= 8, the latency-optimal layout while
+// the batch leaves wave slots free
+// ---------------------------------------------------------------------------------------------------------------
+#include "regime_grid.h"
+
+__global__ __launch_bounds__(64) void k_regime_fwd_grid(const float *logits, const float *init_logits, const float *gumbel,
+                                                        const float *P, float *y_seq, float *log_q, float *log_p, int T, int K,
+                                                        float tau, const float *tau_dev, int hard) {
+  if (tau_dev) tau = *tau_dev;
+  kvae::rgrid::regime_fwd(logits, init_logits, gumbel, P, y_seq, log_q, log_p, blockIdx.x, T, K, tau, hard);
+}
+__global__ __launch_bounds__(64) void k_regime_bwd_grid(const float *logits, const float *init_logits, const float *gumbel,
+                                                        const float *P, const float *y_seq, const float *g_y, const float *g_lq,
+                                                        const float *g_lp, float *g_logits, float *g_init, int T, int K, float tau,
+                                                        const float *tau_dev) {
+  if (tau_dev) tau = *tau_dev;
+  kvae::rgrid::regime_bwd(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, blockIdx.x, T, K, tau);
+}
+// 1 if launched.  Above ~4096 sequences the chip's wave slots are full and 64 sequences per wavefront (thread-per-sequence)
+// have the better throughput.
+extern "C" int kvae_grid_launch_regime_fwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                                           float *y_seq, float *log_q, float *log_p, int B, int T, int K, float tau,
+                                           const float *tau_dev, int hard, hipStream_t s) {
+  if (K > 8 || B > 4096) return 0;
+  k_regime_fwd_grid<<<dim3(B), dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, log_q, log_p, T, K, tau, tau_dev, hard);
+  return 1;
+}
+extern "C" int kvae_grid_launch_regime_bwd(const float *logits, const float *init_logits, const float *gumbel, const float *P,
+                                           const float *y_seq, const float *g_y, const float *g_lq, const float *g_lp,
+                                           float *g_logits, float *g_init, int B, int T, int K, float tau, const float *tau_dev,
+                                           hipStream_t s) {
+  if (K > 8 || B > 4096) return 0;
+  k_regime_bwd_grid<<<dim3(B), dim3(64), 0, s>>>(logits, init_logits, gumbel, P, y_seq, g_y, g_lq, g_lp, g_logits, g_init, T, K, tau,
+                                                 tau_dev);
+  return 1;
+}

@@ -17,7 +17,7 @@ from kvae.train.synthetic import bouncing_ball
 from kvae.train.train import Trainer
 
 dev = torch.device("cuda:0")
-bargs = argparse.Namespace(dynamics=args.dynamics, modes=3, z_dim=4)
+bargs = argparse.Namespace(dynamics=args.dynamics, modes=3, z_dim=4, seq_len=50)
 cfg, model = bench.build_model(bargs, dev)
 x = bouncing_ball(256, 50, 1234).float().to(dev)
 events = {}

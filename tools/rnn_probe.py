@@ -56,3 +56,17 @@ hh = h.clone().requires_grad_(True)
 y = SmallLinear.apply(hh, w, b, True)
 gy = torch.randn_like(y)
 timeit("linear+softmax bwd (all grads)", lambda: torch.autograd.grad(y, (hh, w, b), gy, retain_graph=True))
+
+from kvae.kalman.lgssm_ops import RegimeChain  # noqa: E402
+for (Br, Tr, Kr) in ((32, 100, 7), (256, 50, 3)):
+    gen = torch.Generator().manual_seed(0)
+    lg = torch.randn(Br, Tr, Kr, Kr, generator=gen).to(dev).requires_grad_(True)
+    il = torch.randn(Br, Kr, generator=gen).to(dev).requires_grad_(True)
+    gm = (-torch.empty(Br, Tr, Kr).exponential_(generator=gen).log()).to(dev)
+    Pm = torch.full((Kr, Kr), 0.1 / (Kr - 1), device=dev)
+    Pm.fill_diagonal_(0.9)
+    with torch.no_grad():
+        timeit(f"regime fwd B={Br} T={Tr} K={Kr}", lambda: RegimeChain.apply(lg, il, gm, Pm, 0.7, False))
+    yq = RegimeChain.apply(lg, il, gm, Pm, 0.7, False)
+    ups = [torch.randn_like(t) for t in yq]
+    timeit(f"regime bwd B={Br} T={Tr} K={Kr}", lambda: torch.autograd.grad(yq, (lg, il), ups, retain_graph=True))
