@@ -244,7 +244,7 @@ def cpu_baseline(args, sd, frames, budget_s=25.0):
     B, T = frames.shape[:2]
     Bs = B if B * T * args.z_dim ** 2 <= 256 * 50 * 16 * 4 else min(B, 32)
     x = frames[:Bs].float()
-    tr = O.OracleTrainer(sd, args.dynamics, lr=7e-3, clip=10.0, beta=1.0, with_metrics=True)
+    tr = O.OracleTrainer(sd, args.dynamics, lr=1e-3, clip=10.0, beta=1.0, with_metrics=True)
     g = torch.Generator().manual_seed(5)
 
     def one():
@@ -319,7 +319,7 @@ def roofline_leg(args, cfg, model, x, n_prof_small=10):
     from kvae import _native
     from kvae.train.train import Trainer
     B, T = args.batch, args.seq_len
-    eager = Trainer(model, use_graph=False, world_size=1, reference_logging=True)   # takes the model over from the captured trainer
+    eager = Trainer(model, lr=1e-3, use_graph=False, world_size=1, reference_logging=True)   # takes the model over from the captured trainer
     for _ in range(3):
         eager.step(x)
     n_prof = n_prof_small if B * T <= 20000 else 4
@@ -450,8 +450,12 @@ def run_workload(args, dev, rank, world, full):
     x = frames.float().to(dev)
 
     capture = "hipgraph"
+    # lr: the reference's TrainingConfig default (train.py:347).  The noise of every workload starts from the same generator state,
+    # whatever ran before it in this process (the `also` entries follow the headline and its CPU leg).
+    torch.manual_seed(4321 + rank)
     mk_trainer = lambda graph, w=world, ov=not args.no_overlap: Trainer(
-        model, use_graph=graph, world_size=w, overlap_lgssm=ov, reference_logging=True, graph_allreduce=args.graph_allreduce)
+        model, lr=1e-3, use_graph=graph, world_size=w, overlap_lgssm=ov, reference_logging=True,
+        graph_allreduce=args.graph_allreduce)
     trainer = mk_trainer(not args.no_graph)
     try:
         for _ in range(max(args.warmup, 1)):

@@ -4,8 +4,9 @@
   python examples/train_bouncing_ball.py --epochs 3                       # 1 GPU
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_bouncing_ball.py
 
-Mirrors the reference's kvae/train/train.py loop (phases omitted): beta schedule, Adam + ExponentialLR and the tau decay
-(both reach the captured hipGraph through device scalars), grad clip 10,
+Mirrors the reference's kvae/train/train.py main loop (:246-336): the three training phases ("vae" with kf_weight 0, then
+"warmup" with the alpha-network frozen, then "all"; each switch re-captures the step's hipGraph once), beta schedule, Adam +
+ExponentialLR and the tau decay (all of which reach the captured graph through device scalars), grad clip 10,
 reference-compatible checkpoints; data come from an .npz (uint8 (N,T,H,W), the reference's format) written on the fly.
 """
 import argparse
@@ -22,7 +23,7 @@ from kvae.dataloader.pymunk_dataset import DeviceBatches, PymunkNPZDataset  # no
 from kvae.model.model import KVAE  # noqa: E402
 from kvae.train.checkpoint import Checkpointer  # noqa: E402
 from kvae.train.synthetic import bouncing_ball  # noqa: E402
-from kvae.train.train import Trainer, end_of_epoch_schedules, init_distributed, train_one_epoch  # noqa: E402
+from kvae.train.train import Trainer, end_of_epoch_schedules, init_distributed, phase_for_epoch, train_one_epoch  # noqa: E402
 from kvae.utils.config import KVAEConfig  # noqa: E402
 
 
@@ -36,6 +37,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--config", default=None, help="reference-style YAML (its `kvae:` section becomes the KVAEConfig)")
     ap.add_argument("--decay-steps", type=int, default=1, help="epochs between LR decays (reference default: 20)")
+    ap.add_argument("--pretrain-vae-epochs", type=int, default=1, help="epochs of phase 'vae' (reference default: 5)")
+    ap.add_argument("--warmup-epochs", type=int, default=1, help="epochs of phase 'warmup' (reference default: 10)")
     args = ap.parse_args()
     rank, world, dev = init_distributed()
     out = Path(args.out or tempfile.mkdtemp(prefix="kvae_run_"))
@@ -56,12 +59,20 @@ def main():
     ck = Checkpointer(out / "checkpoints", ckpt_every=0) if rank == 0 else None
     if rank == 0:
         print(cfg.describe(), f"| {world} rank(s), {len(loader)} steps/epoch")
+    tau_start = max(1, args.pretrain_vae_epochs + args.warmup_epochs + 1)   # train.py:244 there
+    phase = None
     for epoch in range(1, args.epochs + 1):
+        want, kf_w, vae_w = phase_for_epoch(epoch, args.pretrain_vae_epochs, args.warmup_epochs)
+        if want != phase:
+            phase = want
+            trainer.set_training_phase(phase, kf_weight=kf_w, vae_weight=vae_w)
+            if rank == 0:
+                print(f"=== training phase '{phase}' from epoch {epoch} (kf_weight {kf_w}) ===")
         trainer.set_beta(model.scheduler.get_beta(epoch) if cfg.scheduled_beta else 1.0)
         stats = train_one_epoch(trainer, loader, dev)
-        lr, tau = end_of_epoch_schedules(trainer, sched, epoch, decay_steps=args.decay_steps)
+        lr, tau = end_of_epoch_schedules(trainer, sched, epoch, decay_steps=args.decay_steps, tau_decay_start_epoch=tau_start)
         if rank == 0:
-            print(f"epoch {epoch}: loss {stats['loss']:.4f} elbo_kf {stats['elbo_kf']:.4f} elbo_vae {stats['elbo_vae_total']:.4f}"
+            print(f"epoch {epoch} [{phase}]: loss {stats['loss']:.4f} elbo_kf {stats['elbo_kf']:.4f} elbo_vae {stats['elbo_vae_total']:.4f}"
                   f" | next lr {lr:.3e}" + (f" tau {tau:.3f}" if tau is not None else ""))
             ck.save_checkpoints(stats["loss"], stats["loss"], model, trainer.opt, epoch)
     if world > 1:

@@ -64,8 +64,8 @@ extern "C" int kvae_rnn_launch_wgrad(const kvae_wgrad_problem *probs, int32_t n,
 
 extern "C" int kvae_rnn_launch_linear_fwd(const float *x, int64_t xs, int64_t N, int F, const float *W, const float *b, int O,
                                           int softmax, float *y, hipStream_t s) {
-  const int rows = sl_rows_per_block(F, O);
-  const size_t lds = sizeof(float) * ((size_t)O * F + (size_t)rows * (F + 1));
+  const int rows = sl_rows_per_block(F, O, N);
+  const size_t lds = sizeof(float) * ((size_t)O * (F + 1) + (size_t)rows * (F + 1));
   const dim3 grid((unsigned)((N + rows - 1) / rows));
   if (softmax)
     k_linear_softmax_fwd<<<grid, dim3(256), lds, s>>>(x, xs, N, F, W, b, O, y, rows);
@@ -76,7 +76,7 @@ extern "C" int kvae_rnn_launch_linear_fwd(const float *x, int64_t xs, int64_t N,
 
 extern "C" int kvae_rnn_launch_linear_bwd_input(const float *g, const float *y, int64_t N, int F, const float *W, int O,
                                                 float *g_logit, float *dx, int64_t dxs, hipStream_t s) {
-  const size_t lds = sizeof(float) * O * F;
+  const size_t lds = sizeof(float) * O * (F + 1);
   const int64_t threads = N * ((F + 3) / 4);
   const dim3 grid((unsigned)((threads + 255) / 256));
   if (y)

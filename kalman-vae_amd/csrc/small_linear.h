@@ -17,8 +17,13 @@ constexpr int SL_MAX_F = 128;
 constexpr int SL_SOFTMAX_MAX_O = 16;
 constexpr int SL_BATCH = 10;      // row elements fetched back to back before their FMAs (a load per FMA waits out its latency)
 
-__device__ __forceinline__ void sl_stage_w(const float *__restrict__ W, float *sh, int count) {
-  for (int i = threadIdx.x; i < count; i += blockDim.x) sh[i] = W[i];
+// W [O,F] into LDS with rows padded to F + 1 floats: threads of one row of x that work on different outputs read
+// sh_w[o * (F + 1) + f] for several o at once - with an even row length (F = 50, 100) those fall into two banks
+__device__ __forceinline__ void sl_stage_w_nosync(const float *__restrict__ W, float *sh, int O, int F) {
+  for (int i = threadIdx.x; i < O * F; i += blockDim.x) sh[(i / F) * (F + 1) + (i % F)] = W[i];
+}
+__device__ __forceinline__ void sl_stage_w(const float *__restrict__ W, float *sh, int O, int F) {
+  sl_stage_w_nosync(W, sh, O, F);
   __syncthreads();
 }
 
@@ -48,9 +53,11 @@ __device__ __forceinline__ void sl_stage_rows(const float *__restrict__ x, int64
     }
   }
 }
-__host__ __device__ inline int sl_rows_per_block(int F, int O) {   // what fits 60 KiB of LDS next to W, at most 64
-  const int room = (15360 - O * F) / (F + 1);
-  return room >= 64 ? 64 : (room >= 32 ? 32 : 16);
+__host__ __device__ inline int sl_rows_per_block(int F, int O, int64_t N) {   // what fits 60 KiB of LDS next to W, at most 64;
+  const int room = (15360 - O * (F + 1)) / (F + 1);                             // fewer when that leaves CUs without a block
+  int rows = room >= 64 ? 64 : (room >= 32 ? 32 : 16);
+  while (rows > 16 && N / rows < 256) rows >>= 1;
+  return rows;
 }
 
 // thread per (row, 4 outputs), `rows` rows per block
@@ -58,9 +65,9 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
                                                     const float *__restrict__ W, const float *__restrict__ b, int O,
                                                     float *__restrict__ y, int rows) {
   extern __shared__ float sh_w[];
-  float *sh_x = sh_w + O * F;
+  float *sh_x = sh_w + O * (F + 1);
   const int64_t n0 = (int64_t)blockIdx.x * rows;
-  for (int i = threadIdx.x; i < O * F; i += 256) sh_w[i] = W[i];
+  sl_stage_w_nosync(W, sh_w, O, F);
   sl_stage_rows(x, xs, n0, N, F, rows, sh_x);
   __syncthreads();
   const int OG = (O + 3) / 4;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
       const float xv = xr[f];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (o0 + j < O) acc[j] = fmaf(xv, sh_w[(o0 + j) * F + f], acc[j]);
+        if (o0 + j < O) acc[j] = fmaf(xv, sh_w[(o0 + j) * (F + 1) + f], acc[j]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -90,9 +97,9 @@ __global__ __launch_bounds__(256) void k_linear_softmax_fwd(const float *__restr
                                                             const float *__restrict__ W, const float *__restrict__ b, int O,
                                                             float *__restrict__ y, int rows) {
   extern __shared__ float sh_w[];
-  float *sh_x = sh_w + O * F;
+  float *sh_x = sh_w + O * (F + 1);
   const int64_t n0 = (int64_t)blockIdx.x * rows;
-  for (int i = threadIdx.x; i < O * F; i += 256) sh_w[i] = W[i];
+  sl_stage_w_nosync(W, sh_w, O, F);
   sl_stage_rows(x, xs, n0, N, F, rows, sh_x);
   __syncthreads();
   const int r = threadIdx.x;
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void k_linear_softmax_fwd(const float *__restr
     const float xv = xr[f];
 #pragma unroll
     for (int o = 0; o < SL_SOFTMAX_MAX_O; ++o)
-      if (o < O) acc[o] = fmaf(xv, sh_w[o * F + f], acc[o]);
+      if (o < O) acc[o] = fmaf(xv, sh_w[o * (F + 1) + f], acc[o]);
   }
   float mx = acc[0];
 #pragma unroll
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_input(const float *__restric
                                                           const float *__restrict__ W, int O, float *__restrict__ dx,
                                                           int64_t dxs) {
   extern __shared__ float sh_w[];
-  sl_stage_w(W, sh_w, O * F);
+  sl_stage_w(W, sh_w, O, F);
   const int FG = (F + 3) / 4;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n = idx / FG;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_input(const float *__restric
       if (o0 + u < O) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (f0 + j < F) acc[j] = fmaf(gv[u], sh_w[(o0 + u) * F + f0 + j], acc[j]);
+          if (f0 + j < F) acc[j] = fmaf(gv[u], sh_w[(o0 + u) * (F + 1) + f0 + j], acc[j]);
       }
   }
 #pragma unroll
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void k_linear_softmax_bwd_input(const float *_
                                                                   float *__restrict__ gl_out, float *__restrict__ dx,
                                                                   int64_t dxs) {
   extern __shared__ float sh_w[];
-  sl_stage_w(W, sh_w, O * F);
+  sl_stage_w(W, sh_w, O, F);
   const int FG = (F + 3) / 4;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t n = idx / FG;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void k_linear_softmax_bwd_input(const float *_
     if (o < O) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (f0 + j < F) acc[j] = fmaf(gl[o], sh_w[o * F + f0 + j], acc[j]);
+        if (f0 + j < F) acc[j] = fmaf(gl[o], sh_w[o * (F + 1) + f0 + j], acc[j]);
     }
 #pragma unroll
   for (int j = 0; j < 4; ++j)

@@ -319,3 +319,34 @@ def test_rnn_wgrad_and_small_linear_hostsim(hostsim_backend):
     import parity_cases
     parity_cases.rnn_wgrad_vs_torch("cpu")
     parity_cases.small_linear_vs_torch("cpu")
+
+
+@pytest.mark.parametrize("name,kind", [("phases_lstm_K3", "lstm"), ("phases_switch_K3", "switching")])
+def test_training_phases_hostsim(name, kind, hostsim_backend):
+    """The Trainer's phases (requires_grad toggles, loss weights, frozen parameters skipped by the optimizer) on the host tier:
+    the kernel bodies on the CPU, torch's own Adam (which skips grad None exactly as the GPU path's slot mask does), against
+    the reference's recorded vae -> warmup -> all run."""
+    import parity_cases
+    from kvae import noise
+    from kvae.model.model import KVAE
+    from kvae.train.train import Trainer
+    from kvae.utils.config import KVAEConfig
+    g = load(name)
+    model = KVAE(KVAEConfig(dynamics_model=kind, num_modes=3, scheduled_beta=False))
+    model.load_state_dict(sub(g, "sd."), strict=True)
+    model.train()
+    model.beta = float(g["beta"])
+    tr = Trainer(model, lr=float(g["lr"]), grad_clip_norm=float(g["clip"]), use_graph=False)
+    assert not tr._flat_step
+
+    def run_step(phase, i, kf_weight):
+        assert tr.kf_weight == kf_weight
+        with noise.inject(eps_a=g[f"{phase}.eps_a{i}"], eps_z=g[f"{phase}.eps_z{i}"], gumbel=g.get(f"{phase}.gumbel{i}")):
+            out = tr.step(g[f"frames{i}"].float())
+        return {k: float(out[k]) for k in ("loss", "elbo_kf", "elbo_vae_total")}
+
+    def steps():
+        return [float(tr.opt.state[p]["step"]) if tr.opt.state.get(p) else 0.0 for p in model.parameters()]
+
+    parity_cases.check_phases(g, tr.set_training_phase, run_step, lambda: {k: p.detach().clone() for k, p in model.named_parameters()},
+                              steps, value_tol=1e-4)

@@ -28,7 +28,8 @@ dev = "cuda"
 B, T, n, m, p, K = a.B, a.T, a.n, a.n, 2, a.K
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).to(dev)
-A = (torch.eye(n).repeat(K, 1, 1) + 0.05 * torch.randn(K, n, n, generator=g)).to(dev).requires_grad_(True)
+pert = 0.05 * (2.0 / n ** 0.5) * min(1.0, 50.0 / T)   # the same growth over the sequence at every (n, T), as bench.py's model
+A = (torch.eye(n).repeat(K, 1, 1) + pert * torch.randn(K, n, n, generator=g)).to(dev).requires_grad_(True)
 Bm = (0.05 * r(K, n, m)).requires_grad_(True)
 Cm = (0.3 * r(K, p, n)).requires_grad_(True)
 Qk = (0.02 * torch.eye(n).repeat(K, 1, 1)).to(dev).requires_grad_(True)

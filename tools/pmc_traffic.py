@@ -11,7 +11,7 @@ import json, re, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 GROUPS = {"smooth_fwd": ("k_smooth_fwd",), "smooth_bwd": ("k_smooth_bwd",), "elbo": ("k_elbo",),
           "lstm_fwd": ("k_lstm_fwd",), "lstm_bwd": ("k_lstm_bwd",)}
 
@@ -46,5 +46,9 @@ doc = {"_round": tag, "_source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZ
        "write; 'elbo' sums the probe, the main launch and the (idle) jitter fallback." % tag,
        "B256_T50_n4_lstm_K3": traffic(ROOT / "profiles" / f"{tag}_lgssm_chain_c2_pmc.txt", ()),
        "B512_T200_n16_lstm_K3": traffic(ROOT / "profiles" / f"{tag}_lgssm_chain_c5_pmc.txt", ("_n16", "SDims<16"))}
+for key, name, x2 in (("B32_T100_n4_switching_K7", "c4", ()), ("B512_T200_n16_switching_K3", "c5_switching", ("_n16", "SDims<16"))):
+    f = ROOT / "profiles" / f"{tag}_lgssm_chain_{name}_pmc.txt"
+    if f.exists():
+        doc[key] = traffic(f, x2)
 (ROOT / "profiles" / "pmc_traffic.json").write_text(json.dumps(doc, indent=1) + "\n")
 print(json.dumps(doc, indent=1))
