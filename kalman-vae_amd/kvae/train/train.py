@@ -151,6 +151,7 @@ class Trainer:
         # Both are properties of THIS trainer's step: the model carries them only while _forward_backward runs.
         self.early_kf_backward = self.lgssm_stream is not None and os.environ.get("KVAE_EARLY_KF_BWD", "1") != "0"
         self._graphs = {}          # (x.shape, mask is None) -> captured step
+        self.captures = 0          # hipGraph captures so far (one per batch shape and per phase)
         self.graph_fb = self.graph_opt = None      # the most recently replayed pair (graph_opt: multi-rank cut only)
         self.static_x = self.static_mask = None
         self.out = {}
@@ -433,6 +434,7 @@ class Trainer:
         prev = lib.dll.kvae_dec_up_set_workgroups(self._decoder_workgroups(x.shape[0]))
         # An object the cyclic collector happens to free DURING capture (an older Trainer's hipGraph, a tensor of its pool) makes
         # HIP calls that are illegal while a stream captures, and the process aborts: collect now, and not again until done.
+        self.captures += 1
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
