@@ -60,10 +60,12 @@ def _mask(world, unequal):
     return m
 
 
-def _step(model, world, rank, x, eps_a, eps_z, gum, mask=None):
+def _step(model, world, rank, x, eps_a, eps_z, gum, mask=None, phase=None):
     from kvae import noise
     from kvae.train.train import Trainer
     tr = Trainer(model, use_graph=False, world_size=world)
+    if phase is not None:
+        tr.set_training_phase(phase)
     sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL) if world > 1 else slice(None)
     ea = eps_a.view(-1, T, 2)[sl].reshape(-1, 2)
     with noise.inject(eps_a=ea, eps_z=eps_z[sl], gumbel=gum[sl]):
@@ -71,28 +73,31 @@ def _step(model, world, rank, x, eps_a, eps_z, gum, mask=None):
     return tr, out
 
 
-def _worker(rank, world, port, kind, q, unequal=False):
+def _worker(rank, world, port, kind, q, unequal=False, phase=None):
     torch.set_num_threads(1)
     _setup()
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tr, out = _step(_model(kind), world, rank, *_data(world), mask=_mask(world, unequal))
+    tr, out = _step(_model(kind), world, rank, *_data(world), mask=_mask(world, unequal), phase=phase)
     flat = torch.cat([p.detach().flatten() for p in tr.model.parameters()])
     q.put((rank, flat.numpy().copy(), tr.flat_grad.numpy().copy(), float(out["loss"])))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,unequal", [("lstm", False), ("switching", False), ("switching", True), ("lstm", True)])
-def test_two_rank_step_matches_global_batch(kind, unequal):
+@pytest.mark.parametrize("kind,unequal,phase", [("lstm", False, None), ("switching", False, None), ("switching", True, None),
+                                                ("lstm", True, None), ("lstm", False, "warmup"), ("switching", True, "vae")])
+def test_two_rank_step_matches_global_batch(kind, unequal, phase):
+    """phase: the step under one of the reference's training phases (train.py:142-207) - the frozen parameters' slots of the flat
+    buffer travel through the all-reduce as zeros and must come out untouched on every rank."""
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q, unequal)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q, unequal, phase)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
@@ -104,7 +109,11 @@ def test_two_rank_step_matches_global_batch(kind, unequal):
     assert torch.equal(g0, g1), "all-reduced gradients differ between ranks"
     # single process, global batch
     _setup()
-    tr, out = _step(_model(kind), 1, 0, *_data(world), mask=_mask(world, unequal))
+    tr, out = _step(_model(kind), 1, 0, *_data(world), mask=_mask(world, unequal), phase=phase)
+    if phase is not None:   # what the phase froze did not move on any rank (bit-identical to the initial values)
+        init = torch.cat([p.detach().flatten() for p in _model(kind).parameters()])
+        frozen = torch.cat([torch.full((p.numel(),), not p.requires_grad) for p in tr.model.parameters()])
+        assert bool(frozen.any()) and torch.equal(p0[frozen], init[frozen]) and not torch.equal(p0[~frozen], init[~frozen])
     gref = tr.flat_grad
     assert float((g0 - gref).abs().max() / gref.abs().max()) < 2e-4
     pref = torch.cat([p.detach().flatten() for p in tr.model.parameters()])
