@@ -156,6 +156,8 @@ __global__ __launch_bounds__(64) void k_mix_bwd_final(const float *partials, flo
   if (threadIdx.x == 0) g_base[idx] = acc;
 }
 
+#include "mix_wave.h"
+
 // ---------------------------------------------------------------------------------------------
 // host side: validation, dispatch on (n,m,p), launch
 // ---------------------------------------------------------------------------------------------
@@ -286,6 +288,29 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
   KVAE_DISPATCH(*prob, k_smooth_fwd<D><<<dim3(prob->B), dim3(64), 0, s>>>(*prob, *st, do_filter, do_rts));
   return launch_status("k_smooth_fwd");
 }
+
+// the streaming mixture kernels (mix_wave.h): 16-byte pieces, K base records in registers
+static bool mix_wave_ok(const float *a, const float *b, const float *c, int K, int E) {
+  // (E >= 128: with a record of 40 floats - n = 4 - a wavefront per row leaves 54 lanes idle and the element-wise kernels win)
+  return (E & 3) == 0 && E >= 128 && E <= 768 && K <= 8 && aligned16(b) && aligned16(c) && a != nullptr;
+}
+static int64_t mix_wave_slabs(int64_t rows, int64_t cap) {   // at least 8 rows per wavefront
+  const int64_t want = (rows + 7) / 8;
+  return want < 1 ? 1 : (want > cap ? cap : want);
+}
+#define KVAE_MIXW_DISPATCH(L)                        \
+  do {                                               \
+    const int ej = (E + 255) / 256;                  \
+    if (K <= 4) {                                    \
+      if (ej == 1) L(4, 1);                          \
+      else if (ej == 2) L(4, 2);                     \
+      else L(4, 3);                                  \
+    } else {                                         \
+      if (ej == 1) L(8, 1);                          \
+      else if (ej == 2) L(8, 2);                     \
+      else L(8, 3);                                  \
+    }                                                \
+  } while (0)
 
 extern "C" {
 
@@ -427,6 +452,15 @@ int kvae_mix_fwd(const float *alpha, const float *base, float *out, int64_t rows
   if (!alpha || !base || !out) return KVAE_ERR_NULL;
   if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
   const int64_t total = rows * E;
+  if (mix_wave_ok(alpha, base, out, K, E)) {   // streaming kernels (mix_wave.h)
+    const int64_t slabs = mix_wave_slabs(rows, 4096), per = (rows + slabs - 1) / slabs;   // about four wavefronts per SIMD
+    const dim3 grid((unsigned)((slabs + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define KVAE_MIXW_FWD(KM, EJ) mixw::k_mix_fwd_wave<KM, EJ><<<grid, block, 0, s>>>(alpha, base, out, rows, K, E, per)
+    KVAE_MIXW_DISPATCH(KVAE_MIXW_FWD);
+#undef KVAE_MIXW_FWD
+    return launch_status("k_mix_fwd_wave");
+  }
   hipLaunchKernelGGL(k_mix_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, alpha, base, out,
                      total, K, E);
   return launch_status("k_mix_fwd");
@@ -439,6 +473,20 @@ int kvae_mix_bwd(const float *alpha, const float *base, const float *g_out, floa
   if (!alpha || !base || !g_out || !g_alpha || !g_base || !partials) return KVAE_ERR_NULL;
   if (rows < 1 || K < 1 || K > KVAE_MAX_K || E < 1) return KVAE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  if (mix_wave_ok(alpha, base, g_out, K, E) && aligned16(partials)) {   // one pass over g_out (mix_wave.h)
+    int64_t slabs = mix_wave_slabs(rows, mixw::MAX_SLABS);              // one register-resident base gradient per wavefront
+    const int64_t cap = kvae_mix_bwd_partials(rows);                    // what the caller's partials buffer holds
+    slabs = slabs < cap ? slabs : cap;
+    const int64_t per = (rows + slabs - 1) / slabs;
+    const int nslab = (int)((rows + per - 1) / per);
+    const dim3 grid((unsigned)((nslab + 3) / 4)), block(256);
+#define KVAE_MIXW_BWD(KM, EJ) \
+  mixw::k_mix_bwd_wave<KM, EJ><<<grid, block, 0, s>>>(alpha, base, g_out, g_alpha, partials, rows, K, E, per, nslab, accumulate_alpha)
+    KVAE_MIXW_DISPATCH(KVAE_MIXW_BWD);
+#undef KVAE_MIXW_BWD
+    mixw::k_mix_bwd_fold<<<dim3((unsigned)((K * E + 31) / 32)), block, 0, s>>>(partials, g_base, nslab, K * E);
+    return launch_status("k_mix_bwd_wave");
+  }
   const int64_t ta = rows * K;
   if (E >= 128 && K <= 4)
     k_mix_bwd_alpha_wide<4><<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s>>>(base, g_out, g_alpha, rows, K, E, accumulate_alpha);

@@ -827,3 +827,39 @@ def backward_shard_vs_slices(DEV, B, T, n, slice_b):
             acc[k] += small[k]
     for k, name in enumerate("ABC"):
         assert rel_err(acc[k].cpu(), big[k].cpu()) < 1e-4, name
+
+
+def mix_vs_torch(DEV):
+    """kvae_mix_fwd / kvae_mix_bwd (mixture-of-K step records, reference dyn_param.py:58-60 / switch_dyn_param.py:82-84) against
+    torch.einsum and its autograd: the streaming kernels' shapes (E = 40 / 48 at n = 4, 544 / 768 at n = 16, K = 3, 7, 8), ragged row
+    counts, a K above their limit (element-wise fallback), and the accumulate flag of the C ABI."""
+    import ctypes as C
+    from kvae import _native as N
+    from kvae.kalman.lgssm_ops import MixDynamics
+    g = torch.Generator().manual_seed(31)
+    for Bsz, T, K, E in [(256, 50, 3, 40), (3, 7, 3, 48), (32, 100, 7, 48), (5, 9, 3, 768), (64, 33, 3, 544), (2, 5, 8, 768),
+                         (4, 6, 9, 40), (1, 1, 2, 12), (2, 3, 3, 42)]:
+        alpha = torch.softmax(torch.randn(Bsz, T, K, generator=g), -1)
+        base = torch.randn(K, E, generator=g)
+        up = torch.randn(Bsz, T, E, generator=g)
+        ar, br = alpha.clone().requires_grad_(True), base.clone().requires_grad_(True)
+        ref = torch.einsum("btk,ke->bte", ar, br)
+        (ref * up).sum().backward()
+        ad, bd = alpha.to(DEV).requires_grad_(True), base.to(DEV).requires_grad_(True)
+        out = MixDynamics.apply(ad, bd)
+        (out * up.to(DEV)).sum().backward()
+        assert rel_err(out.detach().cpu(), ref.detach()) < 1e-6, (K, E)
+        assert rel_err(ad.grad.cpu(), ar.grad) < 2e-5 and rel_err(bd.grad.cpu(), br.grad) < 2e-5, (K, E)
+    # accumulate_alpha = 1 through the raw C ABI: g_alpha += ...
+    Bsz, T, K, E = 7, 5, 3, 768
+    alpha = torch.softmax(torch.randn(Bsz * T, K, generator=g), -1).to(DEV)
+    base, gout = torch.randn(K, E, generator=g).to(DEV), torch.randn(Bsz * T, E, generator=g).to(DEV)
+    lib = N.lib_for(alpha)
+    nblk = lib.dll.kvae_mix_bwd_partials(Bsz * T)
+    partials = torch.empty(nblk, K, E, device=alpha.device)
+    g_alpha0 = torch.randn(Bsz * T, K, generator=g).to(DEV)
+    g_alpha, g_base = g_alpha0.clone(), torch.empty_like(base)
+    assert lib.dll.kvae_mix_bwd(N.ptr(alpha), N.ptr(base), N.ptr(gout), N.ptr(g_alpha), N.ptr(g_base), N.ptr(partials), Bsz * T, K, E,
+                                1, N.stream_for(alpha)) == 0
+    assert rel_err((g_alpha - g_alpha0).cpu(), (gout @ base.T).cpu()) < 2e-5
+    assert rel_err(g_base.cpu(), (alpha.T @ gout).cpu()) < 2e-5

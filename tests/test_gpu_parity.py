@@ -321,6 +321,11 @@ def test_enc_mid_gpu(N, side):
     parity_cases.enc_mid_vs_torch(DEV, N, side)
 
 
+def test_mix_gpu():
+    """Mixture-of-K step records on the streaming kernels (one pass over the gradient records) vs torch.einsum autograd."""
+    parity_cases.mix_vs_torch(DEV)
+
+
 def test_rnn_wgrad_gpu():
     """No library GEMM on the path: LSTM / bi-GRU / head parameter gradients on the f32 matrix cores vs torch products."""
     parity_cases.rnn_wgrad_vs_torch(DEV)

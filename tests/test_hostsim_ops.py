@@ -317,6 +317,7 @@ def test_clip_adam_frozen_segments_vs_torch(hostsim_backend):
 
 def test_rnn_wgrad_and_small_linear_hostsim(hostsim_backend):
     import parity_cases
+    parity_cases.mix_vs_torch("cpu")
     parity_cases.rnn_wgrad_vs_torch("cpu")
     parity_cases.small_linear_vs_torch("cpu")
 

@@ -70,3 +70,13 @@ for (Br, Tr, Kr) in ((32, 100, 7), (256, 50, 3)):
     yq = RegimeChain.apply(lg, il, gm, Pm, 0.7, False)
     ups = [torch.randn_like(t) for t in yq]
     timeit(f"regime bwd B={Br} T={Tr} K={Kr}", lambda: torch.autograd.grad(yq, (lg, il), ups, retain_graph=True))
+
+from kvae.kalman.lgssm_ops import MixDynamics  # noqa: E402
+for (Br, Tr, Kr, Er) in ((512, 200, 3, 768), (512, 200, 3, 544), (256, 50, 3, 40)):
+    al = torch.softmax(torch.randn(Br, Tr, Kr, device=dev), -1).requires_grad_(True)
+    bs = torch.randn(Kr, Er, device=dev).requires_grad_(True)
+    with torch.no_grad():
+        timeit(f"mix fwd rows={Br * Tr} K={Kr} E={Er}", lambda: MixDynamics.apply(al, bs))
+    rec = MixDynamics.apply(al, bs)
+    upm = torch.randn_like(rec)
+    timeit(f"mix bwd rows={Br * Tr} K={Kr} E={Er}", lambda: torch.autograd.grad(rec, (al, bs), upm, retain_graph=True))
