@@ -277,7 +277,11 @@ class KVAE(nn.Module):
         out = self.forward(x, u=u, mask=mask)
         _, _, C_list = out["ABC"]
         a_imputed, a_filtered = self.kalman_filter.emission_means(out["mus_smooth"], out["mus_filt"], C_list)
-        dec = lambda a: self._to_pixels(self.decode_sequence(a))
-        return {"x_recon": dec(out["a_samples"]), "x_imputed": dec(a_imputed), "x_filtered": dec(a_filtered),
+        # The reference decodes a_vae again (forward already did: the same pixels) and then the two read-outs one after the other
+        # (model.py:275-290 there).  Frames are independent: forward's reconstruction is returned as it is, and ONE decoder pass
+        # over the concatenated read-outs gives the other two - two decoder passes in all instead of four.
+        x2 = self._to_pixels(self.decode_sequence(torch.cat([a_imputed, a_filtered], 0)))
+        x_imputed, x_filtered = x2.chunk(2, 0)
+        return {"x_recon": out["x_recon"], "x_imputed": x_imputed, "x_filtered": x_filtered,
                 "a_vae": out["a_samples"], "a_imputed": a_imputed, "a_filtered": a_filtered,
                 "state_probs": out["state_probs"]}
