@@ -416,14 +416,16 @@ class Trainer:
                 else:
                     v.zero_()      # state created by the warm-up: back to a fresh optimizer (step 0, zero moments), in place
 
-    def _decoder_workgroups(self, batch):
+    def _decoder_workgroups(self, frames):
         """Persistent decoder-block workgroups for the captured step.  The switching model's side chain (bi-GRU, regime chain,
-        LGSSM, all above the 32 registers per lane the Winograd workgroups leave free) is what the encoder's backward waits
-        for; with 32 of the 256 CUs left to it the step is 7 % shorter at 256 sequences (3.08 -> 2.86 ms, a step at exactly
-        224: 228 gives 3.10), whereas the lstm model's chain is hidden anyway and every CU taken from the decoder costs
-        (2.73 / 2.76 / 2.80 ms at 256 / 248 / 240).  Larger batches hide the chain behind a longer frame pass: full width."""
+        LGSSM, all above the 32 registers per lane the Winograd workgroups leave free) needs CUs of its own while it is what
+        the encoder's backward waits for.  Round 2 found that up to 256 sequences of T = 50; with round 3's side chain (lane-grid
+        regime chain, no library GEMM) the frame pass of configs[1] hides it again and every CU taken from the decoder costs
+        (12800 frames: 2.847 / 2.860 / 2.884 / 2.886 ms at 256 / 248 / 240 / 224 workgroups), while below that the chain is
+        still the critical path (6400 frames: 1.760 at 224 against 1.799; 3200: 1.212 against 1.250; configs[3]: neutral).
+        The lstm model's chain is hidden at every size."""
         dyn = self.model.kalman_filter.dyn_params
-        if (self.lgssm_stream is not None and getattr(dyn, "is_switching_dynamics", False) and batch <= 256
+        if (self.lgssm_stream is not None and getattr(dyn, "is_switching_dynamics", False) and frames < 12800
                 and not self._kf_value_only()):
             return 224
         return 256
@@ -431,7 +433,7 @@ class Trainer:
     def _capture(self, x, mask=None):
         from .. import _native
         lib = _native.lib_for(x)
-        prev = lib.dll.kvae_dec_up_set_workgroups(self._decoder_workgroups(x.shape[0]))
+        prev = lib.dll.kvae_dec_up_set_workgroups(self._decoder_workgroups(x.shape[0] * x.shape[1]))
         # An object the cyclic collector happens to free DURING capture (an older Trainer's hipGraph, a tensor of its pool) makes
         # HIP calls that are illegal while a stream captures, and the process aborts: collect now, and not again until done.
         self.captures += 1
