@@ -1,0 +1,433 @@
+// lgssm_m4.h — filter + RTS smoother for (n, m, p) = (4, 4, 2) in the quad layout of lgssm_q4.h (sixteen sequences per
+// wavefront, lane i of a quad owns row i of every 4x4 matrix) with the 4x4 products on the MATRIX CORES:
+// v_mfma_f32_4x4x1_16B_f32 multiplies sixteen independent 4x4 blocks - one per quad - in one instruction.
+//
+// Why (profiles/r03_q4_fwd_c4_sq.txt, tools/experiments/mfma4_probe.hip): a wavefront of the quad layout issues ~235 vector
+// instructions per filter step and ~370 per smoother step, of which the products (16 DPP-folded FMAs each) and the transposes
+// (~33 DPP moves and selects each) are the bulk, and with 16 wavefronts on the chip at configs[1] the length of that one
+// instruction stream IS the time.  Measured on gfx950: a 4x4x4 product whose result feeds the next product costs 144 clock
+// ticks as 16 v_fmac_f32_dpp and 68 as four dependent 4x4x1 MFMAs.
+//
+// The algebra (R(X) = "rows of X on the lanes of the quad", the register file's view of a matrix):
+//     P(X, Y, C) := four MFMAs with A-operand R(X).c[k], B-operand R(Y).c[k], accumulator R(C)   =   R(Y X^T + C)
+// (lane j of the quad ends up with row j of Y X^T: D[r][j] = sum_k X[r][k] Y[j][k] sits in register r of lane j).  So
+//     A B^T   = P(B, A)                       - the products of the Joseph update and of the smoother are all of this form
+//     A S     = P(S, A)      for an EXACTLY symmetric S (the filtered / smoothed covariances, which are stored symmetrised)
+//     (Z)^T   = the same four MFMAs with the operands exchanged: (Y X^T + C)^T = X Y^T + C^T = P(Y, X, C^T), bit for bit (the
+//               same products summed in the same order) - so no transpose is ever executed: Sigma_p^T, F0^T and Fm^T are
+//               computed next to Sigma_p, F0 and Fm (symmetrise = add and halve), Sigma_p^T of the smoother is read from
+//               memory by columns, and J = (J^T)^T is P(J^T, I) - a product with the identity, exact.
+// Same equations, same summation order per element (k ascending, accumulator first) as lgssm_q4.h / the reference
+// (kalman_filter.py:31-104, 204-237); same outputs and the same aux record (K unmasked | S | J), so the adjoint kernels of
+// lgssm_q4.h take over unchanged.  Everything except the 4x4 solve of the smoother gain is compiler-visible code (builtins, no
+// inline assembly): the MFMA -> VALU / VALU -> MFMA hazards are the compiler's to handle; the solve (inline-asm DPP FMAs of
+// lgssm_q4.h) is fenced by explicit wait states on both sides.
+#pragma once
+#include "lgssm_q4.h"
+
+#if !defined(KVAE_HOSTSIM) && !defined(KV_TPP)
+namespace kvae {
+namespace m4 {
+
+using q4::f2;
+using q4::f4;
+using q4::Mat;
+
+// R(Y X^T + C) from R(X), R(Y), R(C)
+__device__ __forceinline__ Mat P(const Mat &X, const Mat &Y, const Mat &C) {
+  f4 c = f4{C.c[0], C.c[1], C.c[2], C.c[3]};
+  c = __builtin_amdgcn_mfma_f32_4x4x1f32(X.c[0], Y.c[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_4x4x1f32(X.c[1], Y.c[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_4x4x1f32(X.c[2], Y.c[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_4x4x1f32(X.c[3], Y.c[3], c, 0, 0, 0);
+  return Mat{{c[0], c[1], c[2], c[3]}};
+}
+__device__ __forceinline__ Mat P(const Mat &X, const Mat &Y) { return P(X, Y, q4::zero()); }
+// every register of M has landed / may be overwritten: wait states around the inline-asm code of q4::solve, whose reads and
+// writes the compiler's hazard recogniser cannot see (XDL write -> VALU read of a 2-pass MFMA: 5; VALU write -> XDL read: 2)
+__device__ __forceinline__ void settle(Mat &M) { asm volatile("s_nop 7" : "+v"(M.c[0]), "+v"(M.c[1]), "+v"(M.c[2]), "+v"(M.c[3])); }
+
+// all four entries of a quad's vector on every lane of the quad
+struct Vec4 { float c[4]; };
+__device__ __forceinline__ Vec4 spread(float v) { return Vec4{{q4::qb<0>(v), q4::qb<1>(v), q4::qb<2>(v), q4::qb<3>(v)}}; }
+__device__ __forceinline__ float dot(const Mat &Mrow, const Vec4 &v, float acc) {      // acc + sum_c M[i][c] v[c]
+  return fmaf(Mrow.c[3], v.c[3], fmaf(Mrow.c[2], v.c[2], fmaf(Mrow.c[1], v.c[1], fmaf(Mrow.c[0], v.c[0], acc))));
+}
+__device__ __forceinline__ Mat load_cols(const float *X, int i) {   // R(X^T): lane i takes column i of a row-major 4x4
+  return Mat{{X[i], X[4 + i], X[8 + i], X[12 + i]}};
+}
+__device__ __forceinline__ Mat half_sum(const Mat &A, const Mat &B) {
+  Mat S;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) S.c[c] = 0.5f * (A.c[c] + B.c[c]);
+  return S;
+}
+
+struct StepIn {
+  Mat A, Bm, Q, Qt;
+  Vec4 C0, C1;          // the two emission rows, whole, on every lane
+  float Cl0, Cl1, u, mk;
+  f2 y;
+};
+__device__ __forceinline__ void load_step(const q4::StepPtr &p, int i, StepIn &s) {
+  s.A = q4::load_rows(p.A, i), s.Bm = q4::load_rows(p.Bm, i), s.Q = q4::load_rows(p.Q, i);
+  s.Qt = load_cols(p.Q, i);
+  const f4 c0 = *reinterpret_cast<const f4 *>(p.C), c1 = *reinterpret_cast<const f4 *>(p.C + 4);
+  s.C0 = Vec4{{c0[0], c0[1], c0[2], c0[3]}}, s.C1 = Vec4{{c1[0], c1[1], c1[2], c1[3]}};
+  s.Cl0 = p.C[i], s.Cl1 = p.C[4 + i];
+  s.u = p.U[i];
+  s.y = *reinterpret_cast<const f2 *>(p.Y);
+  s.mk = *p.mk;   // raw; the NULL-mask select happens at the point of use (see lgssm_n16.h)
+}
+
+template <bool AUX>
+__device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int b, int i) {
+  const int T = P_.T;
+  const int64_t bT = (int64_t)b * T;
+  Mat Sig = load_cols(P_.Sigma0 + (int64_t)b * P_.Sigma0_sb, i);   // Sigma0^T, so that P(Sig, A) = A Sigma0 for any Sigma0
+  float mu = P_.mu0[(int64_t)b * P_.mu0_sb + i];
+  const float R00 = P_.R[0], R01 = P_.R[1], R10 = P_.R[2], R11 = P_.R[3];
+  const Mat I4 = q4::eye(i);
+  q4::StepPtr ptr;
+  ptr.init(P_, b, 0);
+  StepIn s, nx;
+  load_step(ptr, i, s);
+  nx = s;
+  KV_Q4_DRAIN();
+  // one step: operands in `s`, the next step's fetched into `nx` (the caller alternates the two: no register copies)
+  auto step = [&](int t, const StepIn &s, StepIn &nx) {
+    if (t + 1 < T) ptr.step(1);
+    load_step(ptr, i, nx);                                   // unconditional prefetch, pinned above this step's stores
+    KV_Q4_FENCE();
+    const int64_t q = bT + t;
+    // predict (kalman_filter.py:65-67)
+    const float mup = dot(s.Bm, spread(s.u), dot(s.A, spread(mu), 0.0f));
+    const Mat AS = P(Sig, s.A);                              // A Sig   (Sig symmetric)
+    const Mat Sigp = P(s.A, AS, s.Q);                        // (A Sig) A^T + Q
+    const Mat Sigpt = P(AS, s.A, s.Qt);                      // its transpose, bit for bit
+    q4::store_rows(S.Sigmas_pred + q * 16, Sigp, i);
+    S.mus_pred[q * 4 + i] = mup;
+    // innovation (:73-90): PCT = Sigp C^T (lane i: PCT[i][c]), S = sym(C PCT + R), r = y - C mup
+    const float pct0 = dot(Sigp, s.C0, 0.0f), pct1 = dot(Sigp, s.C1, 0.0f);
+    const float a00 = q4::qsum(s.Cl0 * pct0) + R00, a01 = q4::qsum(s.Cl0 * pct1) + R01;
+    const float a10 = q4::qsum(s.Cl1 * pct0) + R10, a11 = q4::qsum(s.Cl1 * pct1) + R11;
+    const float s00 = 0.5f * (a00 + a00), s01 = 0.5f * (a01 + a10), s11 = 0.5f * (a11 + a11);
+    const float r0 = s.y[0] - q4::qsum(s.Cl0 * mup), r1 = s.y[1] - q4::qsum(s.Cl1 * mup);
+    const q4::Inv2 F = q4::factor2(s00, s01, s11);
+    float ku0, ku1;
+    q4::solve2(F, pct0, pct1, ku0, ku1);                     // unmasked gain K[i][:]
+    if constexpr (AUX) {
+      float *ax = S.aux + q * KV_AUX_N4;
+      *reinterpret_cast<f2 *>(ax + 2 * i) = f2{ku0, ku1};
+      *reinterpret_cast<f4 *>(ax + 8) = f4{s00, s01, s01, s11};
+    }
+    const float mk = P_.mask ? s.mk : 1.0f;
+    const float k0 = mk * ku0, k1 = mk * ku1;                // :92
+    const float muf = mup + k0 * r0 + k1 * r1;               // :96
+    S.mus_filt[q * 4 + i] = muf;
+    // Joseph update (:97-101): M = I - K C ; (M Sigp) M^T + (K R) K^T, and its transpose next to it
+    Mat M, KRK, KRKt;
+    const float kr0 = k0 * R00 + k1 * R10, kr1 = k0 * R01 + k1 * R11;
+    const Vec4 k0v = spread(k0), k1v = spread(k1), kr0v = spread(kr0), kr1v = spread(kr1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      M.c[c] = fmaf(-k1, s.C1.c[c], fmaf(-k0, s.C0.c[c], I4.c[c]));
+      KRK.c[c] = fmaf(kr1, k1v.c[c], kr0 * k0v.c[c]);
+      KRKt.c[c] = fmaf(k1, kr1v.c[c], k0 * kr0v.c[c]);
+    }
+    const Mat T1 = P(Sigpt, M);                              // M Sigp
+    const Mat F0 = P(M, T1, KRK);                            // (M Sigp) M^T + K R K^T
+    const Mat F0t = P(T1, M, KRKt);                          // its transpose, bit for bit
+    Sig = half_sum(F0, F0t);                                 // :101, exactly symmetric
+    q4::store_rows(S.Sigmas_filt + q * 16, Sig, i);
+    mu = muf;
+  };
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    step(t, s, nx);
+    step(t + 1, nx, s);
+  }
+  if (t < T) step(t, s, nx);
+}
+
+template <bool AUX>
+__device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int b, int i, int lane) {
+  const int T = P_.T;
+  const int64_t bT = (int64_t)b * T;
+  Mat SigS = q4::load_rows(S.Sigmas_filt + (bT + T - 1) * 16, i);
+  float mus = S.mus_filt[(bT + T - 1) * 4 + i];
+  q4::store_rows(S.Sigmas_smooth + (bT + T - 1) * 16, SigS, i);
+  S.mus_smooth[(bT + T - 1) * 4 + i] = mus;
+  struct In { Mat Sf, Sp, Spt, A; float muf, mup; } s, nx;
+  int64_t q = bT + (T >= 2 ? T - 2 : 0);
+  const float *pA = stack_at(P_.A, b, T >= 2 ? T - 1 : 0);
+  const int64_t sA = P_.A.st;
+  auto load = [&](In &o) {
+    o.Sf = q4::load_rows(S.Sigmas_filt + q * 16, i);
+    o.Sp = q4::load_rows(S.Sigmas_pred + (q + 1) * 16, i);
+    o.Spt = load_cols(S.Sigmas_pred + (q + 1) * 16, i);
+    o.A = q4::load_rows(pA, i);
+    o.muf = S.mus_filt[q * 4 + i];
+    o.mup = S.mus_pred[(q + 1) * 4 + i];
+  };
+  if (T >= 2) load(s);
+  nx = s;
+  KV_Q4_DRAIN();
+  const Mat I4 = q4::eye(i);
+  auto step = [&](int t, const In &s, In &nx) {
+    const int64_t qt = bT + t;
+    if (t >= 1) q -= 1, pA -= sA;
+    load(nx);
+    KV_Q4_FENCE();
+    // J = Sig_f A^T Sigp^{-1}  <=>  Sigp^T J^T = A Sig_f  (kalman_filter.py:229)
+    Mat W = P(s.Sf, s.A);                                    // A Sig_f   (Sig_f symmetric)
+    settle(W);
+    Mat X = q4::solve(s.Spt, W, i, lane);                    // J^T, rows on lanes (inline-asm Gauss-Jordan of lgssm_q4.h)
+    settle(X);
+    const Mat J = P(X, I4);                                  // (J^T)^T: a product with the identity, exact
+    if constexpr (AUX) q4::store_rows(S.aux + qt * KV_AUX_N4 + 12, J, i);
+    const Mat D = q4::sub(SigS, s.Sp), Dt = q4::sub(SigS, s.Spt);   // D and D^T (SigS symmetric)
+    const Mat G = P(Dt, J);                                  // J D
+    mus = dot(J, spread(mus - s.mup), s.muf);                // :232
+    const Mat Fm = P(J, G, s.Sf);                            // Sig_f + (J D) J^T   (:234)
+    const Mat Fmt = P(G, J, s.Sf);                           // its transpose (Sig_f symmetric)
+    SigS = half_sum(Fm, Fmt);
+    q4::store_rows(S.Sigmas_smooth + qt * 16, SigS, i);
+    S.mus_smooth[qt * 4 + i] = mus;
+  };
+  int t = T - 2;
+  for (; t >= 1; t -= 2) {
+    step(t, s, nx);
+    step(t - 1, nx, s);
+  }
+  if (t >= 0) step(t, s, nx);
+}
+
+
+// =====================================================================================================================
+// backward: the adjoint sweeps of lgssm_q4.h (same equations, same ws hand-off record, same saved gains K | S | J), products on
+// the matrix cores.  Every transpose the quad kernels execute (six per smoother step, seven per filter step) is either a column
+// load of a matrix that is in memory anyway, a second product with the operands exchanged, or a product with the identity.
+// =====================================================================================================================
+__device__ __forceinline__ Vec4 load_vec(const float *v) {   // a 4-vector, whole, on every lane
+  const f4 x = *reinterpret_cast<const f4 *>(v);
+  return Vec4{{x[0], x[1], x[2], x[3]}};
+}
+
+template <bool HAS_FP>
+__device__ __forceinline__ void rts_bwd_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                                              const kvae_lgssm_input_grads &G, float *ws, int b, int i, int lane) {
+  constexpr int WS_REC = q4::WS_REC;
+  const int T = P_.T;
+  const int64_t bT = (int64_t)b * T;
+  float *w = ws + bT * WS_REC;
+  float gsm = U.mus_smooth[bT * 4 + i];
+  Mat gsS = q4::load_rows(U.Sigmas_smooth + bT * 16, i), gsSt = load_cols(U.Sigmas_smooth + bT * 16, i);
+  w[4 + 16 + i] = HAS_FP ? U.mus_pred[bT * 4 + i] : 0.0f;
+  q4::store_rows(w + 4 + 16 + 4, HAS_FP ? q4::load_rows(U.Sigmas_pred + bT * 16, i) : q4::zero(), i);
+  q4::store_rows(gstack_at(G.gA, b, 0), q4::zero(), i);
+  struct In {
+    Mat Sf, Sp, Spt, Ss, At, Jt, uSs, uSst, uSf, uSp;
+    float mup, mus, uMs, uMf, uMp;
+  } s, nx;
+  int64_t q = bT;
+  const float *pA = stack_at(P_.A, b, T >= 2 ? 1 : 0);
+  const int64_t sA = P_.A.st;
+  auto load = [&](In &o) {
+    o.Sf = q4::load_rows(S.Sigmas_filt + q * 16, i);
+    o.Sp = q4::load_rows(S.Sigmas_pred + (q + 1) * 16, i);
+    o.Spt = load_cols(S.Sigmas_pred + (q + 1) * 16, i);
+    o.Ss = q4::load_rows(S.Sigmas_smooth + (q + 1) * 16, i);
+    o.At = load_cols(pA, i);
+    o.Jt = load_cols(S.aux + q * KV_AUX_N4 + 12, i);
+    o.mup = S.mus_pred[(q + 1) * 4 + i];
+    o.mus = S.mus_smooth[(q + 1) * 4 + i];
+    o.uMs = U.mus_smooth[(q + 1) * 4 + i];
+    o.uSs = q4::load_rows(U.Sigmas_smooth + (q + 1) * 16, i);
+    o.uSst = load_cols(U.Sigmas_smooth + (q + 1) * 16, i);
+    if constexpr (HAS_FP) {
+      o.uMf = U.mus_filt[q * 4 + i];
+      o.uSf = q4::load_rows(U.Sigmas_filt + q * 16, i);
+      o.uMp = U.mus_pred[(q + 1) * 4 + i];
+      o.uSp = q4::load_rows(U.Sigmas_pred + (q + 1) * 16, i);
+    }
+  };
+  if (T >= 2) load(s);
+  nx = s;
+  KV_Q4_DRAIN();
+  const Mat I4 = q4::eye(i);
+  auto step = [&](int t, const In &s, In &nx) {
+    if (t + 2 < T) q += 1, pA += sA;
+    load(nx);
+    KV_Q4_FENCE();
+    float *wt = w + (int64_t)t * WS_REC;
+    const Mat gM = half_sum(gsS, gsSt);                               // sym(adjoint of Sig_s[t])
+    const Mat D2 = q4::add(q4::sub(s.Ss, s.Sp), q4::sub(s.Ss, s.Spt));   // D + D^T, D = Sig_s[t+1] - Sig_p[t+1]: symmetric
+    const float dmu = s.mus - s.mup;
+    const Vec4 gsmv = spread(gsm);
+    const Mat Y1 = P(s.Jt, gM), Y1t = P(gM, s.Jt);                    // gM J and its transpose
+    Mat O;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) O.c[c] = dmu * gsmv.c[c];
+    Mat gJt = P(Y1, D2, O);                                           // (Y1 (D^T + D) + gsm dmu^T)^T
+    const Mat gD = P(Y1t, s.Jt), gDt = P(s.Jt, Y1t);                  // J^T Y1 and its transpose
+    const float gdm = dot(s.Jt, gsmv, 0.0f);                          // J^T gsm
+    settle(gJt);
+    Mat gR = q4::solve(s.Sp, gJt, i, lane);                           // Sig_p gR = gJ^T
+    settle(gR);
+    const Mat gRt = P(gR, I4);
+    const Mat gWA = P(s.At, gRt);                                     // gR^T A[t+1]
+    const Mat gP = P(gR, s.Jt);                                       // J^T gR^T
+    const Mat gAs = P(s.Sf, gR);                                      // gR Sig_f: the smoother's share of gA[t+1]
+    q4::store_rows(wt + 4, q4::add(q4::add(HAS_FP ? s.uSf : q4::zero(), gM), gWA), i);
+    q4::store_rows(wt + WS_REC + 4 + 16 + 4, q4::sub(q4::sub(HAS_FP ? s.uSp : q4::zero(), gD), gP), i);
+    q4::store_rows(gstack_at(G.gA, b, t + 1), gAs, i);
+    wt[i] = (HAS_FP ? s.uMf : 0.0f) + gsm;
+    wt[WS_REC + 4 + 16 + i] = (HAS_FP ? s.uMp : 0.0f) - gdm;
+    gsS = q4::add(s.uSs, gD);
+    gsSt = q4::add(s.uSst, gDt);
+    gsm = s.uMs + gdm;
+  };
+  int t = 0;
+  for (; t + 2 < T; t += 2) {
+    step(t, s, nx);
+    step(t + 1, nx, s);
+  }
+  if (t + 1 < T) step(t, s, nx);
+  float *wl = w + (int64_t)(T - 1) * WS_REC;
+  const int64_t ql = bT + T - 1;
+  q4::store_rows(wl + 4, q4::add(HAS_FP ? q4::load_rows(U.Sigmas_filt + ql * 16, i) : q4::zero(), gsS), i);
+  wl[i] = (HAS_FP ? U.mus_filt[ql * 4 + i] : 0.0f) + gsm;
+}
+
+template <bool HAS_GQ>
+__device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S,
+                                                 const kvae_lgssm_input_grads &G, const float *ws, int b, int i, int lane) {
+  constexpr int WS_REC = q4::WS_REC;
+  const int T = P_.T;
+  const int64_t bT = (int64_t)b * T;
+  const float R00 = P_.R[0], R01 = P_.R[1], R10 = P_.R[2], R11 = P_.R[3];
+  const Mat I4 = q4::eye(i);
+  struct In {
+    Mat A, At, Bt, Sig, Sigt, Sp, Spt, wSf, wSft, wSp, gAs;
+    Vec4 C0, C1, u, mu;
+    float Cl0, Cl1, mk, mup, wmf, wmp;
+    f2 y, ku;
+    f4 Sv;
+  } s, nx;
+  q4::StepPtr ptr;
+  ptr.init(P_, b, T - 1);
+  int t_ld = T - 1;
+  auto load = [&](In &o) {
+    const int64_t q = bT + t_ld;
+    o.A = q4::load_rows(ptr.A, i), o.At = load_cols(ptr.A, i), o.Bt = load_cols(ptr.Bm, i);
+    o.C0 = load_vec(ptr.C), o.C1 = load_vec(ptr.C + 4);
+    o.Cl0 = ptr.C[i], o.Cl1 = ptr.C[4 + i];
+    o.u = load_vec(ptr.U);
+    o.y = *reinterpret_cast<const f2 *>(ptr.Y);
+    o.mk = *ptr.mk;
+    const float *pS = t_ld > 0 ? S.Sigmas_filt + (q - 1) * 16 : P_.Sigma0 + (int64_t)b * P_.Sigma0_sb;
+    const float *pm = t_ld > 0 ? S.mus_filt + (q - 1) * 4 : P_.mu0 + (int64_t)b * P_.mu0_sb;
+    o.Sig = q4::load_rows(pS, i), o.Sigt = load_cols(pS, i);
+    o.mu = load_vec(pm);
+    o.Sp = q4::load_rows(S.Sigmas_pred + q * 16, i), o.Spt = load_cols(S.Sigmas_pred + q * 16, i);
+    o.mup = S.mus_pred[q * 4 + i];
+    const float *ax = S.aux + q * KV_AUX_N4;
+    o.ku = *reinterpret_cast<const f2 *>(ax + 2 * i);
+    o.Sv = *reinterpret_cast<const f4 *>(ax + 8);
+    const float *w = ws + q * WS_REC;
+    o.wmf = w[i];
+    o.wSf = q4::load_rows(w + 4, i), o.wSft = load_cols(w + 4, i);
+    o.wmp = w[4 + 16 + i];
+    o.wSp = q4::load_rows(w + 4 + 16 + 4, i);
+    o.gAs = q4::load_rows(gstack_at(G.gA, b, t_ld), i);
+  };
+  load(s);
+  nx = s;
+  KV_Q4_DRAIN();
+  float gmu = 0.0f;
+  Mat gSig = q4::zero(), gSigt = q4::zero();
+  auto step = [&](int t, const In &s, In &nx) {
+    if (t >= 1) t_ld = t - 1, ptr.step(-1);
+    load(nx);
+    KV_Q4_FENCE();
+    const int64_t q = bT + t;
+    const float mk = P_.mask ? s.mk : 1.0f;
+    gmu += s.wmf;
+    gSig = q4::add(gSig, s.wSf), gSigt = q4::add(gSigt, s.wSft);
+    const Mat Gm = half_sum(gSig, gSigt);
+    const float k0 = mk * s.ku[0], k1 = mk * s.ku[1];
+    const Vec4 k0v = spread(k0), k1v = spread(k1);
+    Mat M, Mt;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      M.c[c] = fmaf(-k1, s.C1.c[c], fmaf(-k0, s.C0.c[c], I4.c[c]));
+      Mt.c[c] = fmaf(-k1v.c[c], s.Cl1, fmaf(-k0v.c[c], s.Cl0, I4.c[c]));
+    }
+    const float gr0 = q4::qsum(k0 * gmu), gr1 = q4::qsum(k1 * gmu);   // gr = K^T gmu
+    const float r0 = s.y[0] - q4::qsum(s.Cl0 * s.mup), r1 = s.y[1] - q4::qsum(s.Cl1 * s.mup);
+    const Mat Sp2 = q4::add(s.Sp, s.Spt);                             // symmetric
+    const Mat X1 = P(Mt, Gm), X1t = P(Gm, Mt);                        // G (I - K C) and its transpose
+    const Mat gIKC = P(Sp2, X1), gIKCt = P(X1, Sp2);                  // X1 (Sig_p^T + Sig_p) and its transpose
+    Mat gSp = P(X1t, Mt, s.wSp);                                      // (I - K C)^T X1 + handed-off
+    (void)M;
+    // gK = G K (R^T + R) - gIKC C^T + gmu r^T   (lane i: row i)
+    const float GK0 = dot(Gm, k0v, 0.0f), GK1 = dot(Gm, k1v, 0.0f);
+    const float gK0 = GK0 * (R00 + R00) + GK1 * (R01 + R10) - dot(gIKC, s.C0, 0.0f) + gmu * r0;
+    const float gK1 = GK0 * (R10 + R01) + GK1 * (R11 + R11) - dot(gIKC, s.C1, 0.0f) + gmu * r1;
+    // Z = S^{-T} (mask gK^T): column i on lane i
+    const q4::Inv2 F = q4::factor2(s.Sv[0], s.Sv[1], s.Sv[3]);
+    float z0, z1;
+    q4::solve2(F, mk * gK0, mk * gK1, z0, z1);
+    const float zk00 = q4::qsum(z0 * s.ku[0]), zk01 = q4::qsum(z0 * s.ku[1]), zk10 = q4::qsum(z1 * s.ku[0]),
+                zk11 = q4::qsum(z1 * s.ku[1]);
+    const float h00 = -0.5f * (zk00 + zk00), h01 = -0.5f * (zk01 + zk10), h11 = -0.5f * (zk11 + zk11);
+    const float gCP0 = h00 * s.Cl0 + h01 * s.Cl1, gCP1 = h01 * s.Cl0 + h11 * s.Cl1;   // gCP = gS0 C (lane j: column j)
+    const Vec4 gCP0v = spread(gCP0), gCP1v = spread(gCP1);
+    // gSp += Z^T C + C^T gCP
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      gSp.c[c] = fmaf(s.Cl1, gCP1v.c[c], fmaf(s.Cl0, gCP0v.c[c], fmaf(z1, s.C1.c[c], fmaf(z0, s.C0.c[c], gSp.c[c]))));
+    // gC = -K^T gIKC + Z Sig_p + gS0 (C Sig_p) + gCP Sig_p^T - gr mu_p^T    (lane j: column j)
+    const float cp0 = dot(s.Spt, s.C0, 0.0f), cp1 = dot(s.Spt, s.C1, 0.0f);
+    const float gC0 = -dot(gIKCt, k0v, 0.0f) + dot(s.Spt, spread(z0), 0.0f) + (h00 * cp0 + h01 * cp1) + dot(s.Sp, gCP0v, 0.0f) -
+                      gr0 * s.mup;
+    const float gC1 = -dot(gIKCt, k1v, 0.0f) + dot(s.Spt, spread(z1), 0.0f) + (h01 * cp0 + h11 * cp1) + dot(s.Sp, gCP1v, 0.0f) -
+                      gr1 * s.mup;
+    float *gCo = gstack_at(G.gC, b, t);
+    gCo[i] = gC0, gCo[4 + i] = gC1;
+    const float gmp = gmu + s.wmp - (s.Cl0 * gr0 + s.Cl1 * gr1);      // gmp = gmu + handed-off - C^T gr
+    G.gY[q * 2 + (i & 1)] = (i & 1) ? gr1 : gr0;
+    if constexpr (HAS_GQ) q4::store_rows(gstack_at(G.gQ, b, t), gSp, i);
+    // gA[t] = smoother share + gSp^T (A Sig) + (gSp A) Sig^T + gmp mu^T ; carried adjoints for t-1
+    const Mat gSpt = P(gSp, I4);
+    const Mat ASt = P(s.A, s.Sigt);                                   // (A Sig)^T
+    const Mat gAS = P(s.At, gSp), gASt = P(gSp, s.At);                // gSp A and its transpose
+    Mat gA;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gA.c[c] = fmaf(gmp, s.mu.c[c], s.gAs.c[c]);
+    gA = P(s.Sig, gAS, gA);                                           // + (gSp A) Sig^T
+    gA = P(ASt, gSpt, gA);                                            // + gSp^T (A Sig)
+    q4::store_rows(gstack_at(G.gA, b, t), gA, i);
+    gSig = P(gASt, s.At), gSigt = P(s.At, gASt);                      // A^T (gSp A) and its transpose
+    const Vec4 gmpv = spread(gmp);
+    gmu = dot(s.At, gmpv, 0.0f);                                      // A^T gmp
+    Mat gB;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) gB.c[c] = gmp * s.u.c[c];
+    q4::store_rows(gstack_at(G.gB, b, t), gB, i);
+    G.gU[q * 4 + i] = dot(s.Bt, gmpv, 0.0f);                          // B^T gmp
+  };
+  int t = T - 1;
+  for (; t >= 1; t -= 2) {
+    step(t, s, nx);
+    step(t - 1, nx, s);
+  }
+  if (t >= 0) step(t, s, nx);
+  if (G.g_mu0) G.g_mu0[(int64_t)b * 4 + i] = gmu;
+  if (G.g_Sigma0) q4::store_rows(G.g_Sigma0 + (int64_t)b * 16, gSig, i);
+}
+
+}  // namespace m4
+}  // namespace kvae
+#endif
