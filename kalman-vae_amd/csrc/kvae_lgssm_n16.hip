@@ -142,11 +142,15 @@ __global__ __launch_bounds__(64) void k_smooth_fwd_m4(kvae_lgssm_problem P, kvae
   const int lane = threadIdx.x & 63, i = lane & 3;
   int b = blockIdx.x * 16 + (lane >> 2);
   b = b < P.B ? b : P.B - 1;
-  if (do_filter) {
-    m4::filter_sweep<AUX>(P, S, b, i);
+  if (do_filter && do_rts) {       // the filter sweep leaves the smoother gains behind (lgssm_m4.h: HOIST)
+    m4::filter_sweep<AUX, true>(P, S, b, i, lane);
     __syncthreads();
+    m4::rts_sweep<AUX, true>(P, S, b, i, lane);
+  } else if (do_filter) {
+    m4::filter_sweep<AUX, false>(P, S, b, i, lane);
+  } else if (do_rts) {
+    m4::rts_sweep<AUX, false>(P, S, b, i, lane);
   }
-  if (do_rts) m4::rts_sweep<AUX>(P, S, b, i, lane);
 }
 extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                    hipStream_t s) {

@@ -63,6 +63,41 @@ __device__ __forceinline__ Mat half_sum(const Mat &A, const Mat &B) {
   return S;
 }
 
+// ---- 4x4 solve  M X = W  (rows of M and of W on the lanes) in natural order ---------------------------------------------------
+// The reference calls torch.linalg.solve (getrf, partial pivoting).  Both systems of this path have a predicted covariance as
+// their matrix - symmetric positive definite, for which elimination without exchanges is backward stable - so the fast path
+// eliminates in natural order (as lgssm_n16.h does): straight-line, compiler-visible code the scheduler can overlap with the
+// products around it.  It watches the pivots; one that is not positive and finite sets `bad`, and the caller repeats the solve
+// with q4::solve (getrf's pivot sequence) at the end of the step.  Without an exchange the two produce the same bits.
+template <int K>
+__device__ __forceinline__ void gj_natural(Mat &m, Mat &x, float &my_rinv, bool &bad, int i) {
+  const float piv = q4::qb<K>(m.c[K]);
+  bad |= !(piv > 0.0f && piv < INFINITY);
+  const float rinv = q4::frcp(piv);
+  const float f = i == K ? 0.0f : -(m.c[K] * rinv);
+  my_rinv = i == K ? rinv : my_rinv;
+#pragma unroll
+  for (int c = K + 1; c < 4; ++c) m.c[c] = fmaf(q4::qb<K>(m.c[c]), f, m.c[c]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) x.c[c] = fmaf(q4::qb<K>(x.c[c]), f, x.c[c]);
+  if constexpr (K + 1 < 4) gj_natural<K + 1>(m, x, my_rinv, bad, i);
+}
+__device__ __forceinline__ Mat solve_natural(Mat m, Mat x, int i, bool &bad) {
+  float my_rinv = 0.0f;
+  bad = false;
+  gj_natural<0>(m, x, my_rinv, bad, i);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) x.c[c] *= my_rinv;
+  return x;
+}
+__device__ __forceinline__ Mat solve_pivoted(Mat m, Mat x, int i, int lane) {   // the rare path: inline-asm code, fenced
+  settle(m);
+  settle(x);
+  Mat r = q4::solve(m, x, i, lane);
+  settle(r);
+  return r;
+}
+
 struct StepIn {
   Mat A, Bm, Q, Qt;
   Vec4 C0, C1;          // the two emission rows, whole, on every lane
@@ -80,8 +115,17 @@ __device__ __forceinline__ void load_step(const q4::StepPtr &p, int i, StepIn &s
   s.mk = *p.mk;   // raw; the NULL-mask select happens at the point of use (see lgssm_n16.h)
 }
 
+// HOIST: the smoother gain J_{t-1} = Sig_f[t-1] A_t^T Sig_p[t]^{-1} (kalman_filter.py:229) does not depend on anything the
+// backward recursion carries, and its operands - A_t Sig_f[t-1], Sig_p[t]^T - are in registers in filter step t.  It is
+// computed there, off the filter's dependent chain (the scheduler fills the chain's latency with it), and left in the aux
+// record (or, for a caller without one, in the Sigmas_smooth slot of t-1, which the smoother overwrites after reading it).
 template <bool AUX>
-__device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int b, int i) {
+__device__ __forceinline__ float *gain_slot(const kvae_lgssm_states &S, int64_t q) {
+  return AUX ? S.aux + q * KV_AUX_N4 + 12 : S.Sigmas_smooth + q * 16;
+}
+
+template <bool AUX, bool HOIST>
+__device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int b, int i, int lane) {
   const int T = P_.T;
   const int64_t bT = (int64_t)b * T;
   Mat Sig = load_cols(P_.Sigma0 + (int64_t)b * P_.Sigma0_sb, i);   // Sigma0^T, so that P(Sig, A) = A Sigma0 for any Sigma0
@@ -105,6 +149,12 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const
     const Mat AS = P(Sig, s.A);                              // A Sig   (Sig symmetric)
     const Mat Sigp = P(s.A, AS, s.Q);                        // (A Sig) A^T + Q
     const Mat Sigpt = P(AS, s.A, s.Qt);                      // its transpose, bit for bit
+    bool bad = false;
+    if constexpr (HOIST) {                                   // Sig_p[t]^T J^T = A_t Sig_f[t-1]; step 0 writes a dummy into slot 0
+      const Mat X = solve_natural(Sigpt, AS, i, bad);
+      q4::store_rows(gain_slot<AUX>(S, t > 0 ? q - 1 : q), P(X, I4), i);
+      bad = bad && t > 0;
+    }
     q4::store_rows(S.Sigmas_pred + q * 16, Sigp, i);
     S.mus_pred[q * 4 + i] = mup;
     // innovation (:73-90): PCT = Sigp C^T (lane i: PCT[i][c]), S = sym(C PCT + R), r = y - C mup
@@ -141,6 +191,9 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const
     Sig = half_sum(F0, F0t);                                 // :101, exactly symmetric
     q4::store_rows(S.Sigmas_filt + q * 16, Sig, i);
     mu = muf;
+    if constexpr (HOIST) {
+      if (__any(bad)) q4::store_rows(gain_slot<AUX>(S, q - 1), P(solve_pivoted(Sigpt, AS, i, lane), I4), i);
+    }
   };
   int t = 0;
   for (; t + 1 < T; t += 2) {
@@ -150,7 +203,7 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const
   if (t < T) step(t, s, nx);
 }
 
-template <bool AUX>
+template <bool AUX, bool HAVE_J>
 __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int b, int i, int lane) {
   const int T = P_.T;
   const int64_t bT = (int64_t)b * T;
@@ -158,7 +211,7 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kv
   float mus = S.mus_filt[(bT + T - 1) * 4 + i];
   q4::store_rows(S.Sigmas_smooth + (bT + T - 1) * 16, SigS, i);
   S.mus_smooth[(bT + T - 1) * 4 + i] = mus;
-  struct In { Mat Sf, Sp, Spt, A; float muf, mup; } s, nx;
+  struct In { Mat Sf, Sp, Spt, A; float muf, mup; } s, nx;   // A: the gain J_t itself when the filter sweep left it (HAVE_J)
   int64_t q = bT + (T >= 2 ? T - 2 : 0);
   const float *pA = stack_at(P_.A, b, T >= 2 ? T - 1 : 0);
   const int64_t sA = P_.A.st;
@@ -166,7 +219,7 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kv
     o.Sf = q4::load_rows(S.Sigmas_filt + q * 16, i);
     o.Sp = q4::load_rows(S.Sigmas_pred + (q + 1) * 16, i);
     o.Spt = load_cols(S.Sigmas_pred + (q + 1) * 16, i);
-    o.A = q4::load_rows(pA, i);
+    o.A = q4::load_rows(HAVE_J ? gain_slot<AUX>(S, q) : pA, i);
     o.muf = S.mus_filt[q * 4 + i];
     o.mup = S.mus_pred[(q + 1) * 4 + i];
   };
@@ -179,13 +232,16 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kv
     if (t >= 1) q -= 1, pA -= sA;
     load(nx);
     KV_Q4_FENCE();
-    // J = Sig_f A^T Sigp^{-1}  <=>  Sigp^T J^T = A Sig_f  (kalman_filter.py:229)
-    Mat W = P(s.Sf, s.A);                                    // A Sig_f   (Sig_f symmetric)
-    settle(W);
-    Mat X = q4::solve(s.Spt, W, i, lane);                    // J^T, rows on lanes (inline-asm Gauss-Jordan of lgssm_q4.h)
-    settle(X);
-    const Mat J = P(X, I4);                                  // (J^T)^T: a product with the identity, exact
-    if constexpr (AUX) q4::store_rows(S.aux + qt * KV_AUX_N4 + 12, J, i);
+    Mat J = s.A;
+    if constexpr (!HAVE_J) {
+      // J = Sig_f A^T Sigp^{-1}  <=>  Sigp^T J^T = A Sig_f  (kalman_filter.py:229)
+      const Mat W = P(s.Sf, s.A);                            // A Sig_f   (Sig_f symmetric)
+      bool bad;
+      Mat X = solve_natural(s.Spt, W, i, bad);               // J^T, rows on lanes
+      if (__any(bad)) X = solve_pivoted(s.Spt, W, i, lane);
+      J = P(X, I4);                                          // (J^T)^T: a product with the identity, exact
+      if constexpr (AUX) q4::store_rows(S.aux + qt * KV_AUX_N4 + 12, J, i);
+    }
     const Mat D = q4::sub(SigS, s.Sp), Dt = q4::sub(SigS, s.Spt);   // D and D^T (SigS symmetric)
     const Mat G = P(Dt, J);                                  // J D
     mus = dot(J, spread(mus - s.mup), s.muf);                // :232
@@ -269,24 +325,26 @@ __device__ __forceinline__ void rts_bwd_sweep(const kvae_lgssm_problem &P_, cons
     Mat O;
 #pragma unroll
     for (int c = 0; c < 4; ++c) O.c[c] = dmu * gsmv.c[c];
-    Mat gJt = P(Y1, D2, O);                                           // (Y1 (D^T + D) + gsm dmu^T)^T
+    const Mat gJt = P(Y1, D2, O);                                         // (Y1 (D^T + D) + gsm dmu^T)^T
     const Mat gD = P(Y1t, s.Jt), gDt = P(s.Jt, Y1t);                  // J^T Y1 and its transpose
     const float gdm = dot(s.Jt, gsmv, 0.0f);                          // J^T gsm
-    settle(gJt);
-    Mat gR = q4::solve(s.Sp, gJt, i, lane);                           // Sig_p gR = gJ^T
-    settle(gR);
-    const Mat gRt = P(gR, I4);
-    const Mat gWA = P(s.At, gRt);                                     // gR^T A[t+1]
-    const Mat gP = P(gR, s.Jt);                                       // J^T gR^T
-    const Mat gAs = P(s.Sf, gR);                                      // gR Sig_f: the smoother's share of gA[t+1]
-    q4::store_rows(wt + 4, q4::add(q4::add(HAS_FP ? s.uSf : q4::zero(), gM), gWA), i);
-    q4::store_rows(wt + WS_REC + 4 + 16 + 4, q4::sub(q4::sub(HAS_FP ? s.uSp : q4::zero(), gD), gP), i);
-    q4::store_rows(gstack_at(G.gA, b, t + 1), gAs, i);
+    auto finish = [&](const Mat &gR) {                                // everything that hangs off the solve: stores only
+      const Mat gRt = P(gR, I4);
+      const Mat gWA = P(s.At, gRt);                                   // gR^T A[t+1]
+      const Mat gP = P(gR, s.Jt);                                     // J^T gR^T
+      const Mat gAs = P(s.Sf, gR);                                    // gR Sig_f: the smoother's share of gA[t+1]
+      q4::store_rows(wt + 4, q4::add(q4::add(HAS_FP ? s.uSf : q4::zero(), gM), gWA), i);
+      q4::store_rows(wt + WS_REC + 4 + 16 + 4, q4::sub(q4::sub(HAS_FP ? s.uSp : q4::zero(), gD), gP), i);
+      q4::store_rows(gstack_at(G.gA, b, t + 1), gAs, i);
+    };
+    bool bad;
+    finish(solve_natural(s.Sp, gJt, i, bad));                         // Sig_p gR = gJ^T
     wt[i] = (HAS_FP ? s.uMf : 0.0f) + gsm;
     wt[WS_REC + 4 + 16 + i] = (HAS_FP ? s.uMp : 0.0f) - gdm;
     gsS = q4::add(s.uSs, gD);
     gsSt = q4::add(s.uSst, gDt);
     gsm = s.uMs + gdm;
+    if (__any(bad)) finish(solve_pivoted(s.Sp, gJt, i, lane));
   };
   int t = 0;
   for (; t + 2 < T; t += 2) {
