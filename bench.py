@@ -362,8 +362,8 @@ def roofline_leg(args, cfg, model, x, n_prof_small=10):
         ach = chain[dom]["GBps"]
         n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
         n16 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (16, 16, 2)
-        kname = {"smooth_fwd": "k_smooth_fwd_q4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
-                 "smooth_bwd": "k_smooth_bwd_q4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
+        kname = {"smooth_fwd": "k_smooth_fwd_m4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
+                 "smooth_bwd": "k_smooth_bwd_m4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
                  "elbo": "k_elbo_tpp(+probe)" if n4 else ("k_elbo4_n16 / k_elbo_n16 (+probe)" if n16 else "k_elbo(+probe)")}[dom]
         roofline = {"kernel": kname,
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -134,7 +134,9 @@ __device__ __forceinline__ void store_w(float *v, f4 x, int g) { *reinterpret_ca
 // factor 1), so the fast path eliminates in natural order: no pivot search, no wave-uniform branch, every broadcast a
 // compile-time DPP row_newbcast.  It watches the pivots; a non-positive or non-finite one (learned Q that is not PSD - the
 // reference's own stability recipe produces such matrices) sends the whole solve to the pivoted elimination below, which
-// follows getrf's pivot sequence (first maximum of |column|) and multipliers.
+// follows getrf's pivot sequence (first maximum of |column|) and multipliers.  (Watching the multipliers as well - partial
+// pivoting keeps them <= 1 - was tried: a bound of 16 sends ordinary covariances of the configs[4] shard down the slow path,
+// 289 -> 745 us for the smoother sweep, and does not move the error of the indefinite test case.)
 __device__ __forceinline__ float frcp(float x) {   // 1/x: hardware reciprocal + one Newton step (<= 1 ulp)
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(fmaf(-x, r, 1.0f), r, r);
@@ -309,19 +311,23 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P, const 
   f4 Sig = load_c(P.Sigma0 + (int64_t)b * P.Sigma0_sb, j, g);      // C-layout of the prior itself: no symmetry assumed
   f4 muW = load_w(P.mu0 + (int64_t)b * P.mu0_sb, g);
   const float R[4] = {P.R[0], P.R[1], P.R[2], P.R[3]};
-  StepIn s, nx;
+  StepIn s0, s1, s2;
   StepPtr ptr;
   ptr.init(P, b);
-  load_step(ptr, j, g, s);
-  nx = s;
+  load_step(ptr, j, g, s0);
+  if (T > 1) ptr.advance();
+  load_step(ptr, j, g, s1);
+  s2 = s1;
   // Drain the preamble's loads HERE.  The s_waitcnt pass is not path-sensitive: loads still pending at loop entry become a
   // vmcnt(0) at the loop top, which on every later iteration waits for the previous step's STORES (vmcnt counts both).
   KV_DRAIN_VMEM();
-  for (int t = 0; t < T; ++t) {
-    // next step's operands fly while this one computes.  Unconditional (the last iteration re-reads its own step): a branch
-    // around the prefetch makes the s_waitcnt pass merge two timelines and wait for this step's stores at the loop top.
-    if (t + 1 < T) ptr.advance();
-    load_step(ptr, j, g, nx);
+  // One step.  The operands of step t + 2 fly while steps t and t + 1 compute: an HBM miss costs about one step of this sweep,
+  // and a register copy of a prefetched value waits for its load, so the three operand sets rotate by NAME (the caller is
+  // unrolled three times) instead of being copied.  Unconditional (the last iterations re-read the last step): a branch around
+  // the prefetch makes the s_waitcnt pass merge two timelines and wait for this step's stores at the loop top.
+  auto step = [&](int t, const StepIn &s, StepIn &far) {
+    if (t + 2 < T) ptr.advance();
+    load_step(ptr, j, g, far);
     KV_PREFETCH_FENCE();
     const int64_t q = bT + t;
     // predict (kalman_filter.py:65-67): (A Sig) A^T + Q in the reference's association order
@@ -358,8 +364,15 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P, const 
     Sig = symmetrise(F0, L, j, g);
     store_rows(S.Sigmas_filt + q * NN, Sig, j, g);                  // symmetric: rows == columns
     muW = mufW;
-    s = nx;
+  };
+  int t = 0;
+  for (; t + 2 < T; t += 3) {
+    step(t, s0, s2);
+    step(t + 1, s1, s0);
+    step(t + 2, s2, s1);
   }
+  if (t < T) step(t, s0, s2);
+  if (t + 1 < T) step(t + 1, s1, s0);
 }
 
 template <bool AUX>
@@ -371,7 +384,7 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P, const kva
   float musL = S.mus_filt[(bT + T - 1) * N + j];
   store_rows(S.Sigmas_smooth + (bT + T - 1) * NN, SigS, j, g);
   S.mus_smooth[(bT + T - 1) * N + j] = musL;
-  struct In { f4 Sf, Spc, At; float mufL, mupL; } s, nx;
+  struct In { f4 Sf, Spc, At; float mufL, mupL; } s0, s1, s2;
   // running pointers of step t: Sigma_f[t], mu_f[t], Sigma_p[t+1], mu_p[t+1], A[t+1]
   const float *pSf = S.Sigmas_filt + (bT + T - 2) * NN, *pSp = S.Sigmas_pred + (bT + T - 1) * NN;
   const float *pmf = S.mus_filt + (bT + T - 2) * N, *pmp = S.mus_pred + (bT + T - 1) * N;
@@ -384,12 +397,18 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P, const kva
     o.mufL = pmf[j];
     o.mupL = pmp[j];
   };
-  if (T >= 2) load(s);
-  nx = s;
+  auto back = [&]() { pSf -= NN, pSp -= NN, pmf -= N, pmp -= N, pA -= sA; };
+  if (T >= 2) load(s0);
+  s1 = s0;
+  if (T >= 3) {
+    back();
+    load(s1);
+  }
+  s2 = s1;
   KV_DRAIN_VMEM();                      // see filter_sweep
-  for (int t = T - 2; t >= 0; --t) {
-    if (t >= 1) pSf -= NN, pSp -= NN, pmf -= N, pmp -= N, pA -= sA;
-    load(nx);                                                       // unconditional, see filter_sweep
+  auto step = [&](int t, const In &s, In &far) {                    // operands two steps ahead, rotated by name: see filter_sweep
+    if (t >= 2) back();
+    load(far);                                                      // unconditional, see filter_sweep
     KV_PREFETCH_FENCE();
     const int64_t q = bT + t;
     // J = Sig_f A^T Sigp^{-1}  <=>  Sigp^T J^T = A Sig_f  (kalman_filter.py:229)
@@ -405,8 +424,15 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P, const kva
     const f4 dW = l2w(musL - s.mupL, lane);
     musL = s.mufL + mtv(Jt, dW);                                    // :232
     S.mus_smooth[q * N + j] = musL;   // the four row-groups store the same value: no branch around a store
-    s = nx;
+  };
+  int t = T - 2;
+  for (; t >= 2; t -= 3) {
+    step(t, s0, s2);
+    step(t - 1, s1, s0);
+    step(t - 2, s2, s1);
   }
+  if (t >= 0) step(t, s0, s2);
+  if (t >= 1) step(t - 1, s1, s0);
 }
 
 
