@@ -43,6 +43,15 @@ __device__ __forceinline__ Mat P(const Mat &X, const Mat &Y, const Mat &C) {
   return Mat{{c[0], c[1], c[2], c[3]}};
 }
 __device__ __forceinline__ Mat P(const Mat &X, const Mat &Y) { return P(X, Y, q4::zero()); }
+// rank-one terms on the same instruction: R(C + y x^T) for two vectors held one entry per lane (lane j gets y_j x_r in register
+// r) - outer products without broadcasting either vector over the quad
+__device__ __forceinline__ Mat outer1(float x, float y, const Mat &C) {
+  const f4 c = __builtin_amdgcn_mfma_f32_4x4x1f32(x, y, f4{C.c[0], C.c[1], C.c[2], C.c[3]}, 0, 0, 0);
+  return Mat{{c[0], c[1], c[2], c[3]}};
+}
+__device__ __forceinline__ Mat outer2(float x0, float y0, float x1, float y1, const Mat &C) {   // C + y0 x0^T + y1 x1^T
+  return outer1(x1, y1, outer1(x0, y0, C));
+}
 // every register of M has landed / may be overwritten: wait states around the inline-asm code of q4::solve, whose reads and
 // writes the compiler's hazard recogniser cannot see (XDL write -> VALU read of a 2-pass MFMA: 5; VALU write -> XDL read: 2)
 __device__ __forceinline__ void settle(Mat &M) { asm volatile("s_nop 7" : "+v"(M.c[0]), "+v"(M.c[1]), "+v"(M.c[2]), "+v"(M.c[3])); }
@@ -176,15 +185,10 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const
     const float muf = mup + k0 * r0 + k1 * r1;               // :96
     S.mus_filt[q * 4 + i] = muf;
     // Joseph update (:97-101): M = I - K C ; (M Sigp) M^T + (K R) K^T, and its transpose next to it
-    Mat M, KRK, KRKt;
     const float kr0 = k0 * R00 + k1 * R10, kr1 = k0 * R01 + k1 * R11;
-    const Vec4 k0v = spread(k0), k1v = spread(k1), kr0v = spread(kr0), kr1v = spread(kr1);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      M.c[c] = fmaf(-k1, s.C1.c[c], fmaf(-k0, s.C0.c[c], I4.c[c]));
-      KRK.c[c] = fmaf(kr1, k1v.c[c], kr0 * k0v.c[c]);
-      KRKt.c[c] = fmaf(k1, kr1v.c[c], k0 * kr0v.c[c]);
-    }
+    const Mat M = outer2(s.Cl0, -k0, s.Cl1, -k1, I4);        // I - k0 C0^T - k1 C1^T
+    const Mat KRK = outer2(k0, kr0, k1, kr1, q4::zero());    // (K R) K^T
+    const Mat KRKt = outer2(kr0, k0, kr1, k1, q4::zero());   // K (K R)^T
     const Mat T1 = P(Sigpt, M);                              // M Sigp
     const Mat F0 = P(M, T1, KRK);                            // (M Sigp) M^T + K R K^T
     const Mat F0t = P(T1, M, KRKt);                          // its transpose, bit for bit
@@ -416,19 +420,13 @@ __device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P_, c
     const Mat Gm = half_sum(gSig, gSigt);
     const float k0 = mk * s.ku[0], k1 = mk * s.ku[1];
     const Vec4 k0v = spread(k0), k1v = spread(k1);
-    Mat M, Mt;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      M.c[c] = fmaf(-k1, s.C1.c[c], fmaf(-k0, s.C0.c[c], I4.c[c]));
-      Mt.c[c] = fmaf(-k1v.c[c], s.Cl1, fmaf(-k0v.c[c], s.Cl0, I4.c[c]));
-    }
+    const Mat Mt = outer2(-k0, s.Cl0, -k1, s.Cl1, I4);                // (I - K C)^T = I - C0 k0^T - C1 k1^T
     const float gr0 = q4::qsum(k0 * gmu), gr1 = q4::qsum(k1 * gmu);   // gr = K^T gmu
     const float r0 = s.y[0] - q4::qsum(s.Cl0 * s.mup), r1 = s.y[1] - q4::qsum(s.Cl1 * s.mup);
     const Mat Sp2 = q4::add(s.Sp, s.Spt);                             // symmetric
     const Mat X1 = P(Mt, Gm), X1t = P(Gm, Mt);                        // G (I - K C) and its transpose
     const Mat gIKC = P(Sp2, X1), gIKCt = P(X1, Sp2);                  // X1 (Sig_p^T + Sig_p) and its transpose
     Mat gSp = P(X1t, Mt, s.wSp);                                      // (I - K C)^T X1 + handed-off
-    (void)M;
     // gK = G K (R^T + R) - gIKC C^T + gmu r^T   (lane i: row i)
     const float GK0 = dot(Gm, k0v, 0.0f), GK1 = dot(Gm, k1v, 0.0f);
     const float gK0 = GK0 * (R00 + R00) + GK1 * (R01 + R10) - dot(gIKC, s.C0, 0.0f) + gmu * r0;
@@ -443,9 +441,7 @@ __device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P_, c
     const float gCP0 = h00 * s.Cl0 + h01 * s.Cl1, gCP1 = h01 * s.Cl0 + h11 * s.Cl1;   // gCP = gS0 C (lane j: column j)
     const Vec4 gCP0v = spread(gCP0), gCP1v = spread(gCP1);
     // gSp += Z^T C + C^T gCP
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      gSp.c[c] = fmaf(s.Cl1, gCP1v.c[c], fmaf(s.Cl0, gCP0v.c[c], fmaf(z1, s.C1.c[c], fmaf(z0, s.C0.c[c], gSp.c[c]))));
+    gSp = outer2(gCP0, s.Cl0, gCP1, s.Cl1, outer2(s.Cl0, z0, s.Cl1, z1, gSp));
     // gC = -K^T gIKC + Z Sig_p + gS0 (C Sig_p) + gCP Sig_p^T - gr mu_p^T    (lane j: column j)
     const float cp0 = dot(s.Spt, s.C0, 0.0f), cp1 = dot(s.Spt, s.C1, 0.0f);
     const float gC0 = -dot(gIKCt, k0v, 0.0f) + dot(s.Spt, spread(z0), 0.0f) + (h00 * cp0 + h01 * cp1) + dot(s.Sp, gCP0v, 0.0f) -
