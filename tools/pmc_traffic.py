@@ -6,7 +6,7 @@ HBM bytes per launch = corrected FETCH_SIZE + WRITE_SIZE (KB in the summaries). 
 section): x2 for the n = 16 kernels, whose reads are 16-byte-per-lane row loads covering >= 128 contiguous bytes (checked: 2 x
 269.4 MB = 539 MB against 5.4 KB x 102400 steps = 553 MB of known reads of k_smooth_fwd_n16; WRITE_SIZE 446 MB == the 4.36 KB x
 102400 it stores); x1 for the n = 4 kernels (a quad reads 64 contiguous bytes: 2.21 MB fetched against 2.36 MB of known
-operand reads of k_smooth_fwd_q4) and for the LSTM kernels (4-byte-per-lane accesses, calibrated in round 1)."""
+operand reads of the quad-layout forward kernel, round 2; the matrix-core version, k_smooth_fwd_m4, reads the same lines) and for the LSTM kernels (4-byte-per-lane accesses, calibrated in round 1)."""
 import json, re, sys
 from pathlib import Path
 
