@@ -226,7 +226,7 @@ extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const fl
 extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *mus, const float *Sigs, const float *eps,
                                      float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
                                      const kvae_lgssm_input_grads *g, int have_g, hipStream_t s);
-// kvae_lgssm_n16.hip (lgssm_q4.h): (n, m, p) = (4, 4, 2), sixteen sequences per wavefront
+// kvae_lgssm_n16.hip (lgssm_m4.h over the quad layout of lgssm_q4.h): (n, m, p) = (4, 4, 2), sixteen sequences per wavefront
 extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                    hipStream_t s);
 extern "C" void kvae_q4_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
@@ -269,7 +269,7 @@ static int launch_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *s
   if (q4_ok(prob) && aligned16(st->Sigmas_filt) && aligned16(st->Sigmas_pred) && aligned16(st->Sigmas_smooth) &&
       aligned16(st->aux)) {
     kvae_q4_launch_fwd(prob, st, do_filter, do_rts, s);
-    return launch_status("k_smooth_fwd_q4");
+    return launch_status("k_smooth_fwd_m4");
   }
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && (st->aux || !do_filter)) {
     // rts-only calls need no gains; filter calls use the fused-phase kernel when the caller provides aux
@@ -369,7 +369,7 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (with_rts && (!saved->mus_smooth || !saved->Sigmas_smooth)) return KVAE_ERR_NULL;
   if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
-  if (with_rts && saved->aux && q4_ok(prob)) {   // sixteen sequences per wavefront (lgssm_q4.h)
+  if (with_rts && saved->aux && q4_ok(prob)) {   // sixteen sequences per wavefront (lgssm_m4.h)
     const int fp = (up->mus_filt != nullptr) + (up->Sigmas_filt != nullptr) + (up->mus_pred != nullptr) + (up->Sigmas_pred != nullptr);
     const auto gs16 = [](const kvae_gstack &g) { return !g.ptr || (aligned16(g.ptr) && g.sb % 4 == 0 && g.st % 4 == 0); };
     const bool al = aligned16(saved->Sigmas_filt) && aligned16(saved->Sigmas_pred) && aligned16(saved->Sigmas_smooth) &&
@@ -377,7 +377,7 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
                     aligned16(up->Sigmas_pred) && gs16(out->gA) && gs16(out->gB) && gs16(out->gQ) && aligned16(out->g_Sigma0);
     if (up->mus_smooth && up->Sigmas_smooth && (fp == 0 || fp == 4) && al && out->gU) {
       kvae_q4_launch_bwd(prob, saved, up, out, ws, fp == 4, s);
-      return launch_status("k_smooth_bwd_q4");
+      return launch_status("k_smooth_bwd_m4");
     }
   }
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {

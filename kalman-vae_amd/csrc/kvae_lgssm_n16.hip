@@ -124,19 +124,9 @@ extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *m
   else k_elbo_n16<true, false><<<grid, block, 0, s>>>(*p, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, *g);
 }
 
-// ---- (n, m, p) = (4, 4, 2): sixteen sequences per wavefront, rows on the lanes of a quad (lgssm_q4.h); grid = ceil(B / 16) ----
-template <bool AUX>
-__global__ __launch_bounds__(64) void k_smooth_fwd_q4(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
-  const int lane = threadIdx.x & 63, i = lane & 3;
-  int b = blockIdx.x * 16 + (lane >> 2);
-  b = b < P.B ? b : P.B - 1;     // a ragged last wavefront recomputes (and re-stores, identically) the last sequence: no branch
-  if (do_filter) {
-    q4::filter_sweep<AUX>(P, S, b, i);
-    __syncthreads();
-  }
-  if (do_rts) q4::rts_sweep<AUX>(P, S, b, i, lane);
-}
-// the same sweeps with the 4x4 products on the matrix cores (lgssm_m4.h)
+// ---- (n, m, p) = (4, 4, 2): sixteen sequences per wavefront, rows on the lanes of a quad, 4x4 products on the matrix cores
+// (lgssm_m4.h over the layout of lgssm_q4.h); grid = ceil(B / 16); a ragged last wavefront recomputes (and re-stores, identically)
+// the last sequence: no branch ----
 template <bool AUX>
 __global__ __launch_bounds__(64) void k_smooth_fwd_m4(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
   const int lane = threadIdx.x & 63, i = lane & 3;
@@ -155,26 +145,10 @@ __global__ __launch_bounds__(64) void k_smooth_fwd_m4(kvae_lgssm_problem P, kvae
 extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                    hipStream_t s) {
   const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
-  static const int m4_env = getenv("KVAE_M4") ? atoi(getenv("KVAE_M4")) : 1;   // 0: DPP products (lgssm_q4.h), A/B runs
-  if (m4_env) {
-    if (st->aux) k_smooth_fwd_m4<true><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
-    else k_smooth_fwd_m4<false><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
-    return;
-  }
-  if (st->aux) k_smooth_fwd_q4<true><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
-  else k_smooth_fwd_q4<false><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
+  if (st->aux) k_smooth_fwd_m4<true><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
+  else k_smooth_fwd_m4<false><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
 }
 
-template <bool HAS_FP, bool HAS_GQ>
-__global__ __launch_bounds__(64) void k_smooth_bwd_q4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
-                                                      kvae_lgssm_input_grads G, float *ws) {
-  const int lane = threadIdx.x & 63, i = lane & 3;
-  int b = blockIdx.x * 16 + (lane >> 2);
-  b = b < P.B ? b : P.B - 1;
-  q4::rts_bwd_sweep<HAS_FP>(P, S, U, G, ws, b, i, lane);
-  __syncthreads();
-  q4::filter_bwd_sweep<HAS_GQ>(P, S, G, ws, b, i, lane);
-}
 template <bool HAS_FP, bool HAS_GQ>
 __global__ __launch_bounds__(64) void k_smooth_bwd_m4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
                                                       kvae_lgssm_input_grads G, float *ws) {
@@ -189,16 +163,8 @@ extern "C" void kvae_q4_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm
                                    const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s) {
   const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
   const bool gq = out->gQ.ptr != nullptr;
-  static const int m4_env = getenv("KVAE_M4") ? atoi(getenv("KVAE_M4")) : 1;   // 0: DPP products (lgssm_q4.h), A/B runs
-  if (m4_env) {
-    if (has_fp && gq) k_smooth_bwd_m4<true, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-    else if (has_fp) k_smooth_bwd_m4<true, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-    else if (gq) k_smooth_bwd_m4<false, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-    else k_smooth_bwd_m4<false, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-    return;
-  }
-  if (has_fp && gq) k_smooth_bwd_q4<true, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-  else if (has_fp) k_smooth_bwd_q4<true, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-  else if (gq) k_smooth_bwd_q4<false, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-  else k_smooth_bwd_q4<false, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
+  if (has_fp && gq) k_smooth_bwd_m4<true, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
+  else if (has_fp) k_smooth_bwd_m4<true, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
+  else if (gq) k_smooth_bwd_m4<false, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
+  else k_smooth_bwd_m4<false, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
 }

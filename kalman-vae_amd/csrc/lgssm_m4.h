@@ -1,11 +1,11 @@
-// lgssm_m4.h — filter + RTS smoother for (n, m, p) = (4, 4, 2) in the quad layout of lgssm_q4.h (sixteen sequences per
-// wavefront, lane i of a quad owns row i of every 4x4 matrix) with the 4x4 products on the MATRIX CORES:
+// lgssm_m4.h — filter + RTS smoother and their adjoints for (n, m, p) = (4, 4, 2) in the quad layout of lgssm_q4.h (sixteen
+// sequences per wavefront, lane i of a quad owns row i of every 4x4 matrix) with the 4x4 products on the MATRIX CORES:
 // v_mfma_f32_4x4x1_16B_f32 multiplies sixteen independent 4x4 blocks - one per quad - in one instruction.
 //
-// Why (profiles/r03_q4_fwd_c4_sq.txt, tools/experiments/mfma4_probe.hip): a wavefront of the quad layout issues ~235 vector
-// instructions per filter step and ~370 per smoother step, of which the products (16 DPP-folded FMAs each) and the transposes
-// (~33 DPP moves and selects each) are the bulk, and with 16 wavefronts on the chip at configs[1] the length of that one
-// instruction stream IS the time.  Measured on gfx950: a 4x4x4 product whose result feeds the next product costs 144 clock
+// Why (profiles/r03_q4_fwd_c4_sq.txt, tools/experiments/mfma4_probe.hip): a wavefront of the DPP version of these sweeps issued
+// ~235 vector instructions per filter step and ~370 per smoother step, of which the products (16 DPP-folded FMAs each) and the
+// transposes (~33 DPP moves and selects each) were the bulk, and with 16 wavefronts on the chip at configs[1] the length of that
+// one instruction stream IS the time.  Measured on gfx950: a 4x4x4 product whose result feeds the next product costs 144 clock
 // ticks as 16 v_fmac_f32_dpp and 68 as four dependent 4x4x1 MFMAs.
 //
 // The algebra (R(X) = "rows of X on the lanes of the quad", the register file's view of a matrix):
@@ -15,13 +15,15 @@
 //     A S     = P(S, A)      for an EXACTLY symmetric S (the filtered / smoothed covariances, which are stored symmetrised)
 //     (Z)^T   = the same four MFMAs with the operands exchanged: (Y X^T + C)^T = X Y^T + C^T = P(Y, X, C^T), bit for bit (the
 //               same products summed in the same order) - so no transpose is ever executed: Sigma_p^T, F0^T and Fm^T are
-//               computed next to Sigma_p, F0 and Fm (symmetrise = add and halve), Sigma_p^T of the smoother is read from
-//               memory by columns, and J = (J^T)^T is P(J^T, I) - a product with the identity, exact.
-// Same equations, same summation order per element (k ascending, accumulator first) as lgssm_q4.h / the reference
-// (kalman_filter.py:31-104, 204-237); same outputs and the same aux record (K unmasked | S | J), so the adjoint kernels of
-// lgssm_q4.h take over unchanged.  Everything except the 4x4 solve of the smoother gain is compiler-visible code (builtins, no
-// inline assembly): the MFMA -> VALU / VALU -> MFMA hazards are the compiler's to handle; the solve (inline-asm DPP FMAs of
-// lgssm_q4.h) is fenced by explicit wait states on both sides.
+//               computed next to Sigma_p, F0 and Fm (symmetrise = add and halve), a matrix that is in memory anyway is read by
+//               columns, and J = (J^T)^T is P(J^T, I) - a product with the identity, exact.
+//     y x^T   = ONE MFMA on two vectors held one entry per lane (outer1): I - K C, K R K^T and the rank-one terms of the adjoint
+//               need no quad broadcast.
+// Same equations, same summation order per element (k ascending, accumulator first) as the reference
+// (kalman_filter.py:31-104, 204-237; adjoint: lgssm_bwd.h); same outputs, aux record (K unmasked | S | J) and ws hand-off record
+// as lgssm_n4.h.  Everything except the pivoted 4x4 solve is compiler-visible code (builtins, no inline assembly): the
+// MFMA -> VALU / VALU -> MFMA hazards are the compiler's to handle; the pivoted solve (inline-asm DPP FMAs of lgssm_q4.h, the
+// rare path) is fenced by explicit wait states on both sides.  tools/m4_selftest.hip checks every primitive against plain loops.
 #pragma once
 #include "lgssm_q4.h"
 

@@ -3,7 +3,7 @@
 ELBO, backward - with the algorithmic GB/s of SURVEY.md section 8(d) next to each.  Defaults: the BASELINE configs[4] shard.
   python3 tools/lgssm_probe.py [--n 16] [--B 512] [--T 200] [--iters 10] [--q-per-step] [--mask] [--check]
 A/B switches (read once per process): KVAE_N16=0 generic kernels for n = 16; KVAE_Q4=0 one wavefront per sequence for
-n = 4 (lgssm_n4.h) instead of sixteen sequences per wavefront (lgssm_q4.h)."""
+n = 4 (lgssm_n4.h) instead of sixteen sequences per wavefront (lgssm_m4.h)."""
 import argparse
 import sys
 from pathlib import Path
