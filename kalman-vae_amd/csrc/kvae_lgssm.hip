@@ -239,8 +239,10 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 static bool stack16(const kvae_stack &s) { return aligned16(s.ptr) && s.sb % 4 == 0 && s.st % 4 == 0; }
 static bool q4_ok(const kvae_lgssm_problem *p) {
   static const int env = getenv("KVAE_Q4") ? atoi(getenv("KVAE_Q4")) : 1;   // 0: one wavefront per sequence (A/B runs)
-  return env && p->n == 4 && p->m == 4 && p->p == 2 && stack16(p->A) && stack16(p->Bm) && stack16(p->Q) &&
-         aligned16(p->Sigma0) && p->Sigma0_sb % 4 == 0 && (reinterpret_cast<uintptr_t>(p->Y) & 7u) == 0;
+  // lgssm_m4.h reads A, B, Q and the two rows of C as 16-byte rows, and (the adjoint) u_t and the previous mean whole
+  return env && p->n == 4 && p->m == 4 && p->p == 2 && stack16(p->A) && stack16(p->Bm) && stack16(p->Q) && stack16(p->C) &&
+         aligned16(p->Sigma0) && p->Sigma0_sb % 4 == 0 && aligned16(p->mu0) && p->mu0_sb % 4 == 0 && aligned16(p->U) &&
+         (reinterpret_cast<uintptr_t>(p->Y) & 7u) == 0;
 }
 static bool n16_ok(const kvae_lgssm_problem *p) {
   static const int env = getenv("KVAE_N16") ? atoi(getenv("KVAE_N16")) : 1;   // 0: generic kernels (A/B runs)
@@ -372,9 +374,10 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (with_rts && saved->aux && q4_ok(prob)) {   // sixteen sequences per wavefront (lgssm_m4.h)
     const int fp = (up->mus_filt != nullptr) + (up->Sigmas_filt != nullptr) + (up->mus_pred != nullptr) + (up->Sigmas_pred != nullptr);
     const auto gs16 = [](const kvae_gstack &g) { return !g.ptr || (aligned16(g.ptr) && g.sb % 4 == 0 && g.st % 4 == 0); };
-    const bool al = aligned16(saved->Sigmas_filt) && aligned16(saved->Sigmas_pred) && aligned16(saved->Sigmas_smooth) &&
-                    aligned16(saved->aux) && aligned16(ws) && aligned16(up->Sigmas_smooth) && aligned16(up->Sigmas_filt) &&
-                    aligned16(up->Sigmas_pred) && gs16(out->gA) && gs16(out->gB) && gs16(out->gQ) && aligned16(out->g_Sigma0);
+    const bool al = aligned16(saved->mus_filt) && aligned16(saved->Sigmas_filt) && aligned16(saved->Sigmas_pred) &&
+                    aligned16(saved->Sigmas_smooth) && aligned16(saved->aux) && aligned16(ws) && aligned16(up->Sigmas_smooth) &&
+                    aligned16(up->Sigmas_filt) && aligned16(up->Sigmas_pred) && gs16(out->gA) && gs16(out->gB) && gs16(out->gQ) &&
+                    aligned16(out->g_Sigma0);
     if (up->mus_smooth && up->Sigmas_smooth && (fp == 0 || fp == 4) && al && out->gU) {
       kvae_q4_launch_bwd(prob, saved, up, out, ws, fp == 4, s);
       return launch_status("k_smooth_bwd_m4");

@@ -11,12 +11,7 @@ using namespace kvae;
 template <bool AUX>   // AUX: also save the gains K | S | J per step for the backward (states.aux)
 __global__ __launch_bounds__(64) void k_smooth_fwd_n16(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
   __shared__ n16::Lds L;
-  const int b = blockIdx.x;
-  if (do_filter) {
-    n16::filter_sweep<AUX>(P, S, b, L);
-    __syncthreads();   // the smoother reads back what this wavefront has just written
-  }
-  if (do_rts) n16::rts_sweep<AUX>(P, S, b, L);
+  n16::smooth_fwd_wave<AUX>(P, S, do_filter, do_rts, L);
 }
 
 extern "C" void kvae_n16_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
@@ -32,10 +27,7 @@ template <bool HAS_FP, bool HAS_GQ>
 __global__ __launch_bounds__(64) void k_smooth_bwd_n16(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
                                                        kvae_lgssm_input_grads G, float *ws) {
   __shared__ n16::Lds L;
-  const int b = blockIdx.x;
-  n16::rts_bwd_sweep<HAS_FP>(P, S, U, G, ws, b, L);
-  __syncthreads();   // the filter sweep reads back the hand-off records this wavefront has just written
-  n16::filter_bwd_sweep<HAS_GQ>(P, S, G, ws, b, L);
+  n16::smooth_bwd_wave<HAS_FP, HAS_GQ>(P, S, U, G, ws, L);
 }
 
 extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
@@ -52,53 +44,35 @@ extern "C" void kvae_n16_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgss
 // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised: a wrong guess is only slower), and step t reads
 // A, B, Q and z of step t + 1 as well: give every XCD one contiguous range of (b, t) so that the neighbour's operands are in
 // ITS L2 instead of being fetched over the fabric a second time (bijective for any grid size).
-__device__ __forceinline__ unsigned xcd_contiguous(unsigned wg, unsigned nwg) {
-  const unsigned q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-}
 __global__ __launch_bounds__(64) void k_elbo_probe_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
                                                        float *zst, int32_t *levels) {
-  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int b = w / P.T, t = w - b * P.T;
-  n16::elbo_probe(P, Sig_s, mus, eps, zst, levels, b, t);
+  n16::elbo_probe_wave(P, Sig_s, mus, eps, zst, levels);
 }
 template <bool GRADS, bool HAS_GQ>
 __global__ __launch_bounds__(64) void k_elbo_n16(kvae_lgssm_problem P, const float *mus, const float *Sigs, const float *eps,
                                                  float *terms, const int32_t *levels, const float *zst, float *g_mus,
                                                  float *g_Sigs, kvae_lgssm_input_grads G) {
   __shared__ n16::ELds L;
-  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int b = w / P.T, t = w - b * P.T;
-  n16::elbo_main<GRADS, HAS_GQ>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t, L);
+  n16::elbo_wave<GRADS, HAS_GQ>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, L);
 }
 
-// shared Q: four steps per wavefront (lgssm_n16_elbo.h, elbo_probe4 / elbo_main4); grid = B * ceil(T / 4)
 __global__ __launch_bounds__(64) void k_elbo_probe4_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
                                                         float *zst, int32_t *levels) {
-  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
-  n16::elbo_probe4(P, Sig_s, mus, eps, zst, levels, b, t0, w == 0 && P.T >= 2);
+  n16::elbo_probe4_wave(P, Sig_s, mus, eps, zst, levels);
 }
 template <bool GRADS>
 __global__ __launch_bounds__(64) void k_elbo4_n16(kvae_lgssm_problem P, const float *mus, const float *Sigs, const float *eps,
                                                   float *terms, const int32_t *levels, const float *zst, float *g_mus,
                                                   float *g_Sigs, kvae_lgssm_input_grads G) {
   __shared__ n16::ELds4 L;
-  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
-  n16::elbo_main4<GRADS>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t0, L);
+  n16::elbo4_wave<GRADS>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, L);
 }
-// z_t again at the resolved level of Sigma_s (lgssm_n16_elbo.h, elbo_zfix); grid = B * ceil(T / 4), every wavefront leaves at its
-// first instruction when that level is 0
 __global__ __launch_bounds__(64) void k_elbo_zfix_n16(kvae_lgssm_problem P, const float *Sig_s, const float *mus, const float *eps,
                                                       float *zst, const int32_t *levels) {
-  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
-  n16::elbo_zfix(P, Sig_s, mus, eps, zst, levels, b, t0);
+  n16::elbo_zfix_wave(P, Sig_s, mus, eps, zst, levels);
 }
-static bool elbo_shared_q(const kvae_lgssm_problem *p) {
-  return p->Q.sb == 0 && p->Q.st == 0;
-}
+// a Q shared by the whole batch (lstm dynamics): the four-steps-per-wavefront layout, unless the caller wants g Q per step
+static bool elbo_shared_q(const kvae_lgssm_problem *p) { return p->Q.sb == 0 && p->Q.st == 0; }
 
 extern "C" void kvae_n16_launch_elbo_probe(const kvae_lgssm_problem *p, const float *Sig_s, const float *mus, const float *eps,
                                            float *zst, int32_t *levels, hipStream_t s) {
@@ -129,18 +103,7 @@ extern "C" void kvae_n16_launch_elbo(const kvae_lgssm_problem *p, const float *m
 // the last sequence: no branch ----
 template <bool AUX>
 __global__ __launch_bounds__(64) void k_smooth_fwd_m4(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
-  const int lane = threadIdx.x & 63, i = lane & 3;
-  int b = blockIdx.x * 16 + (lane >> 2);
-  b = b < P.B ? b : P.B - 1;
-  if (do_filter && do_rts) {       // the filter sweep leaves the smoother gains behind (lgssm_m4.h: HOIST)
-    m4::filter_sweep<AUX, true>(P, S, b, i, lane);
-    __syncthreads();
-    m4::rts_sweep<AUX, true>(P, S, b, i, lane);
-  } else if (do_filter) {
-    m4::filter_sweep<AUX, false>(P, S, b, i, lane);
-  } else if (do_rts) {
-    m4::rts_sweep<AUX, false>(P, S, b, i, lane);
-  }
+  m4::smooth_fwd_wave<AUX>(P, S, do_filter, do_rts);
 }
 extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                    hipStream_t s) {
@@ -152,12 +115,7 @@ extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm
 template <bool HAS_FP, bool HAS_GQ>
 __global__ __launch_bounds__(64) void k_smooth_bwd_m4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
                                                       kvae_lgssm_input_grads G, float *ws) {
-  const int lane = threadIdx.x & 63, i = lane & 3;
-  int b = blockIdx.x * 16 + (lane >> 2);
-  b = b < P.B ? b : P.B - 1;
-  m4::rts_bwd_sweep<HAS_FP>(P, S, U, G, ws, b, i, lane);
-  __syncthreads();
-  m4::filter_bwd_sweep<HAS_GQ>(P, S, G, ws, b, i, lane);
+  m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(P, S, U, G, ws);
 }
 extern "C" void kvae_q4_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                                    const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s) {

@@ -27,7 +27,7 @@
 #pragma once
 #include "lgssm_q4.h"
 
-#if !defined(KVAE_HOSTSIM) && !defined(KV_TPP)
+#if (!defined(KVAE_HOSTSIM) || defined(KVAE_WAVE_EMU)) && !defined(KV_TPP)   // KVAE_WAVE_EMU: tests/hostsim/wave_emu.h
 namespace kvae {
 namespace m4 {
 
@@ -48,7 +48,8 @@ __device__ __forceinline__ Mat P(const Mat &X, const Mat &Y) { return P(X, Y, q4
 // rank-one terms on the same instruction: R(C + y x^T) for two vectors held one entry per lane (lane j gets y_j x_r in register
 // r) - outer products without broadcasting either vector over the quad
 __device__ __forceinline__ Mat outer1(float x, float y, const Mat &C) {
-  const f4 c = __builtin_amdgcn_mfma_f32_4x4x1f32(x, y, f4{C.c[0], C.c[1], C.c[2], C.c[3]}, 0, 0, 0);
+  f4 c = f4{C.c[0], C.c[1], C.c[2], C.c[3]};
+  c = __builtin_amdgcn_mfma_f32_4x4x1f32(x, y, c, 0, 0, 0);
   return Mat{{c[0], c[1], c[2], c[3]}};
 }
 __device__ __forceinline__ Mat outer2(float x0, float y0, float x1, float y1, const Mat &C) {   // C + y0 x0^T + y1 x1^T
@@ -56,7 +57,11 @@ __device__ __forceinline__ Mat outer2(float x0, float y0, float x1, float y1, co
 }
 // every register of M has landed / may be overwritten: wait states around the inline-asm code of q4::solve, whose reads and
 // writes the compiler's hazard recogniser cannot see (XDL write -> VALU read of a 2-pass MFMA: 5; VALU write -> XDL read: 2)
+#if defined(KVAE_WAVE_EMU)
+__device__ __forceinline__ void settle(Mat &) {}
+#else
 __device__ __forceinline__ void settle(Mat &M) { asm volatile("s_nop 7" : "+v"(M.c[0]), "+v"(M.c[1]), "+v"(M.c[2]), "+v"(M.c[3])); }
+#endif
 
 // all four entries of a quad's vector on every lane of the quad
 struct Vec4 { float c[4]; };
@@ -482,6 +487,36 @@ __device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P_, c
   if (t >= 0) step(t, s, nx);
   if (G.g_mu0) G.g_mu0[(int64_t)b * 4 + i] = gmu;
   if (G.g_Sigma0) q4::store_rows(G.g_Sigma0 + (int64_t)b * 16, gSig, i);
+}
+
+
+// ---- the kernels' bodies (kvae_lgssm_n16.hip wraps them in __global__ functions; tests/hostsim runs them on emulated wavefronts):
+// sixteen sequences per wavefront, grid = ceil(B / 16); a ragged last wavefront recomputes (and re-stores, identically) the last
+// sequence: no branch
+template <bool AUX>
+__device__ __forceinline__ void smooth_fwd_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int do_filter, int do_rts) {
+  const int lane = threadIdx.x & 63, i = lane & 3;
+  int b = blockIdx.x * 16 + (lane >> 2);
+  b = b < P_.B ? b : P_.B - 1;
+  if (do_filter && do_rts) {       // the filter sweep leaves the smoother gains behind (HOIST)
+    filter_sweep<AUX, true>(P_, S, b, i, lane);
+    __syncthreads();
+    rts_sweep<AUX, true>(P_, S, b, i, lane);
+  } else if (do_filter) {
+    filter_sweep<AUX, false>(P_, S, b, i, lane);
+  } else if (do_rts) {
+    rts_sweep<AUX, false>(P_, S, b, i, lane);
+  }
+}
+template <bool HAS_FP, bool HAS_GQ>
+__device__ __forceinline__ void smooth_bwd_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                                                const kvae_lgssm_input_grads &G, float *ws) {
+  const int lane = threadIdx.x & 63, i = lane & 3;
+  int b = blockIdx.x * 16 + (lane >> 2);
+  b = b < P_.B ? b : P_.B - 1;
+  rts_bwd_sweep<HAS_FP>(P_, S, U, G, ws, b, i, lane);
+  __syncthreads();
+  filter_bwd_sweep<HAS_GQ>(P_, S, G, ws, b, i, lane);
 }
 
 }  // namespace m4

@@ -25,7 +25,7 @@
 #pragma once
 #include "lgssm_n4.h"   // solve2, stack_at, mask_addr
 
-#if !defined(KVAE_HOSTSIM) && !defined(KV_TPP)
+#if (!defined(KVAE_HOSTSIM) || defined(KVAE_WAVE_EMU)) && !defined(KV_TPP)   // KVAE_WAVE_EMU: tests/hostsim/wave_emu.h
 namespace kvae {
 namespace n16 {
 
@@ -146,7 +146,11 @@ __device__ __forceinline__ float frcp(float x) {   // 1/x: hardware reciprocal +
 // last written by an earlier fmac of the previous elimination step, by an LDS return, or by the s_nop-guarded head of the step.
 template <int K>
 __device__ __forceinline__ void fmac_bcast(float &acc, float f) {
+#if defined(KVAE_WAVE_EMU)
+  acc = fmaf(bcast<K>(acc), f, acc);
+#else
   asm volatile("v_fmac_f32_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(f), "n"(K));
+#endif
 }
 template <int K, int C>
 __device__ __forceinline__ void gj_update_cols(float (&m)[N], float f) {
@@ -160,7 +164,9 @@ __device__ __forceinline__ void gj_eliminate(float (&m)[N], f4 &x, float &my_rin
   const float piv = bcast<K>(m[K]);
   const float rinv = frcp(piv);
   const float f = i == K ? 0.0f : -(m[K] * rinv);
+#if !defined(KVAE_WAVE_EMU)
   asm volatile("s_nop 1");                     // whatever the compiler scheduled last, the DPP reads below are clear of it
+#endif
   gj_update_cols<K, K + 1>(m, f);
 #pragma unroll
   for (int q = 0; q < 4; ++q) x[q] = fmaf(f, bcast<K>(x[q]), x[q]);
@@ -660,6 +666,28 @@ __device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P, co
   }
   if (G.g_mu0) G.g_mu0[(int64_t)b * N + j] = gmuL;
   if (G.g_Sigma0) store_c(G.g_Sigma0 + (int64_t)b * NN, gSig, j, g);
+}
+
+
+// ---- the kernels' bodies (kvae_lgssm_n16.hip wraps them in __global__ functions with the tile in LDS; tests/hostsim runs them on
+// emulated wavefronts): one sequence per wavefront, grid = B
+template <bool AUX>
+__device__ __forceinline__ void smooth_fwd_wave(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, int do_filter, int do_rts,
+                                                Lds &L) {
+  const int b = blockIdx.x;
+  if (do_filter) {
+    filter_sweep<AUX>(P, S, b, L);
+    __syncthreads();   // the smoother reads back what this wavefront has just written
+  }
+  if (do_rts) rts_sweep<AUX>(P, S, b, L);
+}
+template <bool HAS_FP, bool HAS_GQ>
+__device__ __forceinline__ void smooth_bwd_wave(const kvae_lgssm_problem &P, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                                                const kvae_lgssm_input_grads &G, float *ws, Lds &L) {
+  const int b = blockIdx.x;
+  rts_bwd_sweep<HAS_FP>(P, S, U, G, ws, b, L);
+  __syncthreads();   // the filter sweep reads back the hand-off records this wavefront has just written
+  filter_bwd_sweep<HAS_GQ>(P, S, G, ws, b, L);
 }
 
 }  // namespace n16

@@ -606,6 +606,48 @@ __device__ __forceinline__ void elbo_main4(const kvae_lgssm_problem &P, const fl
   }
 }
 
+
+// ---- the kernels' bodies (kvae_lgssm_n16.hip wraps them in __global__ functions with the tiles in LDS).  One wavefront per step (per-step Q) or per four consecutive steps (shared Q); wavefront w of the grid
+// works on the w-th unit of ITS XCD's contiguous share, so that a step and its successor - which read each other's operands -
+// sit in the same L2.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned wg, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+}
+__device__ __forceinline__ void elbo_probe_wave(const kvae_lgssm_problem &P, const float *Sig_s, const float *mus, const float *eps,
+                                                float *zst, int32_t *levels) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = w / P.T, t = w - b * P.T;
+  elbo_probe(P, Sig_s, mus, eps, zst, levels, b, t);
+}
+template <bool GRADS, bool HAS_GQ>
+__device__ __forceinline__ void elbo_wave(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps,
+                                          float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
+                                          const kvae_lgssm_input_grads &G, ELds &L) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int b = w / P.T, t = w - b * P.T;
+  elbo_main<GRADS, HAS_GQ>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t, L);
+}
+__device__ __forceinline__ void elbo_probe4_wave(const kvae_lgssm_problem &P, const float *Sig_s, const float *mus, const float *eps,
+                                                 float *zst, int32_t *levels) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
+  elbo_probe4(P, Sig_s, mus, eps, zst, levels, b, t0, w == 0 && P.T >= 2);
+}
+template <bool GRADS>
+__device__ __forceinline__ void elbo4_wave(const kvae_lgssm_problem &P, const float *mus, const float *Sigs, const float *eps,
+                                           float *terms, const int32_t *levels, const float *zst, float *g_mus, float *g_Sigs,
+                                           const kvae_lgssm_input_grads &G, ELds4 &L) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
+  elbo_main4<GRADS>(P, mus, Sigs, eps, terms, levels, zst, g_mus, g_Sigs, G, b, t0, L);
+}
+__device__ __forceinline__ void elbo_zfix_wave(const kvae_lgssm_problem &P, const float *Sig_s, const float *mus, const float *eps,
+                                               float *zst, const int32_t *levels) {
+  const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int nq = (P.T + 3) >> 2, b = w / nq, t0 = 4 * (w - b * nq);
+  elbo_zfix(P, Sig_s, mus, eps, zst, levels, b, t0);
+}
 }  // namespace n16
 }  // namespace kvae
 #endif

@@ -17,7 +17,7 @@
 #pragma once
 #include "lgssm_n4.h"   // stack_at, mask_addr, KV_AUX_N4
 
-#if !defined(KVAE_HOSTSIM) && !defined(KV_TPP)
+#if (!defined(KVAE_HOSTSIM) || defined(KVAE_WAVE_EMU)) && !defined(KV_TPP)   // KVAE_WAVE_EMU: tests/hostsim/wave_emu.h
 namespace kvae {
 namespace q4 {
 
@@ -26,14 +26,20 @@ using f2 = __attribute__((ext_vector_type(2))) float;
 struct Mat { float c[4]; };   // lane i: row i
 
 // acc += (quad lane K of src) * f
+template <int K> __device__ __forceinline__ void fmac_q(float &acc, float src, float f);
+#if defined(KVAE_WAVE_EMU)
+template <int K> __device__ __forceinline__ void fmac_q(float &acc, float src, float f) {
+  acc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), K * 0x55, 0xf, 0xf, true)), f, acc);
+}
+#else
 #define KV_Q4_DPP(K)                                                                                                        \
   template <> __device__ __forceinline__ void fmac_q<K>(float &acc, float src, float f) {                                  \
     asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[" #K "," #K "," #K "," #K "] row_mask:0xf bank_mask:0xf"            \
                  : "+v"(acc) : "v"(src), "v"(f));                                                                          \
   }
-template <int K> __device__ __forceinline__ void fmac_q(float &acc, float src, float f);
 KV_Q4_DPP(0) KV_Q4_DPP(1) KV_Q4_DPP(2) KV_Q4_DPP(3)
 #undef KV_Q4_DPP
+#endif
 
 // Two wait states between a VALU write and a DPP read of the same register: the compiler's hazard recogniser cannot see
 // into the asm above, so every value that the compiler's own VALU code produced and that is about to be read THROUGH DPP
@@ -50,7 +56,11 @@ __device__ __forceinline__ float qx2(float v) { return dppm<0x4E>(v); }         
 __device__ __forceinline__ float qsum(float x) { x += qx1(x); x += qx2(x); return x; }           // over the quad, all lanes
 __device__ __forceinline__ float qmax(float x) { x = fmaxf(x, qx1(x)); x = fmaxf(x, qx2(x)); return x; }
 
+#if defined(KVAE_WAVE_EMU)
+__device__ __forceinline__ void guard(Mat &) {}
+#else
 __device__ __forceinline__ void guard(Mat &m) { asm volatile("s_nop 1" : "+v"(m.c[0]), "+v"(m.c[1]), "+v"(m.c[2]), "+v"(m.c[3])); }
+#endif
 
 __device__ __forceinline__ Mat sub(const Mat &A, const Mat &B) {
   Mat C;

@@ -114,13 +114,56 @@ static void run_elbo(const kvae_lgssm_problem &P, const float *mus, const float 
     }
 }
 
+// wave_emu_kernels.cpp: the product's wavefront-level kernels ((4,4,2) on lgssm_m4.h, (16,16,2) on lgssm_n16.h) on emulated
+// wavefronts.  Off by default (the bodies above are the fast way to check arithmetic); kvae_hostsim_wave_emu(1) routes the
+// smoother entry points there for the shapes and alignments the GPU dispatch (kvae_lgssm.hip: q4_ok / n16_ok) sends to them.
 extern "C" {
+void kvae_wemu_fwd_n4(const kvae_lgssm_problem *, const kvae_lgssm_states *, int, int);
+void kvae_wemu_bwd_n4(const kvae_lgssm_problem *, const kvae_lgssm_states *, const kvae_lgssm_states *, const kvae_lgssm_input_grads *,
+                      float *, int);
+void kvae_wemu_fwd_n16(const kvae_lgssm_problem *, const kvae_lgssm_states *, int, int);
+void kvae_wemu_bwd_n16(const kvae_lgssm_problem *, const kvae_lgssm_states *, const kvae_lgssm_states *,
+                       const kvae_lgssm_input_grads *, float *, int);
+}
+static int g_wave_emu = 0;
+static bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool stack16(const kvae_stack &s) { return al16(s.ptr) && s.sb % 4 == 0 && s.st % 4 == 0; }
+static bool gstack16(const kvae_gstack &g) { return !g.ptr || (al16(g.ptr) && g.sb % 4 == 0 && g.st % 4 == 0); }
+// the gates of the GPU dispatch (kvae_lgssm.hip: q4_ok / n16_ok and the alignment tests of launch_fwd / kvae_lgssm_smooth_bwd)
+static bool wave_fwd_ok(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int n) {
+  if (!g_wave_emu || p->n != n || p->m != n || p->p != 2) return false;
+  const bool prob = stack16(p->A) && stack16(p->Bm) && stack16(p->Q) && stack16(p->C) && al16(p->Sigma0) && p->Sigma0_sb % 4 == 0 &&
+                    al16(p->mu0) && p->mu0_sb % 4 == 0 && al16(p->U) && (reinterpret_cast<uintptr_t>(p->Y) & 7) == 0;
+  return prob && al16(st->mus_filt) && al16(st->Sigmas_filt) && al16(st->mus_pred) && al16(st->Sigmas_pred) &&
+         al16(st->mus_smooth) && al16(st->Sigmas_smooth) && al16(st->aux);
+}
+static bool wave_bwd_ok(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                        const kvae_lgssm_input_grads *out, const float *ws, int n) {
+  return wave_fwd_ok(p, saved, n) && saved->aux && al16(ws) && al16(up->Sigmas_smooth) && al16(up->Sigmas_filt) &&
+         al16(up->Sigmas_pred) && gstack16(out->gA) && gstack16(out->gB) && gstack16(out->gQ) && al16(out->g_Sigma0) && out->gU;
+}
+
+extern "C" {
+
+int kvae_hostsim_wave_emu(int on) {
+  const int was = g_wave_emu;
+  g_wave_emu = on;
+  return was;
+}
 
 static int fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *st, int do_filter, int do_rts) {
   int rc = check_problem(prob);
   if (rc) return rc;
   if (!st || !st->mus_filt || !st->Sigmas_filt || !st->mus_pred || !st->Sigmas_pred) return KVAE_ERR_NULL;
   if (do_rts && (!st->mus_smooth || !st->Sigmas_smooth)) return KVAE_ERR_NULL;
+  if (wave_fwd_ok(prob, st, 4)) {
+    kvae_wemu_fwd_n4(prob, st, do_filter, do_rts);
+    return KVAE_OK;
+  }
+  if (wave_fwd_ok(prob, st, 16)) {
+    kvae_wemu_fwd_n16(prob, st, do_filter, do_rts);
+    return KVAE_OK;
+  }
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && (st->aux || !do_filter)) {
     run_fwd_n4(*prob, *st, do_filter, do_rts);
     return KVAE_OK;
@@ -138,6 +181,15 @@ int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
   if (rc) return rc;
   if (!saved || !up || !out || !ws) return KVAE_ERR_NULL;
   if (!out->gA.ptr || !out->gB.ptr || !out->gC.ptr || !out->gY) return KVAE_ERR_NULL;
+  if (with_rts && (wave_bwd_ok(prob, saved, up, out, ws, 4) || wave_bwd_ok(prob, saved, up, out, ws, 16))) {
+    // as kvae_lgssm.hip: upstream gradients of the filtered / predicted stacks come all four or not at all
+    const int fp = (up->mus_filt != nullptr) + (up->Sigmas_filt != nullptr) + (up->mus_pred != nullptr) + (up->Sigmas_pred != nullptr);
+    if ((fp == 0 || fp == 4) && up->mus_smooth && up->Sigmas_smooth) {
+      if (prob->n == 4) kvae_wemu_bwd_n4(prob, saved, up, out, ws, fp == 4);
+      else kvae_wemu_bwd_n16(prob, saved, up, out, ws, fp == 4);
+      return KVAE_OK;
+    }
+  }
   if (prob->n == 4 && prob->m == 4 && prob->p == 2 && saved->aux) {
     run_bwd_n4(*prob, *saved, *up, *out, ws, with_rts);
     return KVAE_OK;

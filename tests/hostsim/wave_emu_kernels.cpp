@@ -1,0 +1,54 @@
+// wave_emu_kernels.cpp — TEST-ONLY: the wavefront-level LGSSM kernels of the product ((4,4,2): csrc/lgssm_m4.h over lgssm_q4.h;
+// (16,16,2): csrc/lgssm_n16.h), the same bodies the __global__ functions of kvae_lgssm_n16.hip wrap, run on emulated wavefronts
+// (wave_emu.h) over host pointers.  hostsim.cpp routes its smoother entry points here when kvae_hostsim_wave_emu(1) was called.
+#define KVAE_HOSTSIM 1
+#define KVAE_WAVE_EMU 1
+#include "wave_emu.h"
+
+#include "../../kalman-vae_amd/csrc/lgssm_m4.h"
+#include "../../kalman-vae_amd/csrc/lgssm_n16.h"
+
+using namespace kvae;
+
+static int g_launches[4] = {0, 0, 0, 0};   // emulated launches so far: fwd n4, bwd n4, fwd n16, bwd n16 (tests assert they happened)
+
+extern "C" {
+
+int kvae_wemu_launches(int which) { return which >= 0 && which < 4 ? g_launches[which] : -1; }
+
+void kvae_wemu_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts) {
+  const unsigned grid = (unsigned)((p->B + 15) / 16);
+  g_launches[0] += 1;
+  if (st->aux) wemu::launch(grid, [&] { m4::smooth_fwd_wave<true>(*p, *st, do_filter, do_rts); });
+  else wemu::launch(grid, [&] { m4::smooth_fwd_wave<false>(*p, *st, do_filter, do_rts); });
+}
+void kvae_wemu_bwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                      const kvae_lgssm_input_grads *out, float *ws, int has_fp) {
+  const unsigned grid = (unsigned)((p->B + 15) / 16);
+  const bool gq = out->gQ.ptr != nullptr;
+  g_launches[1] += 1;
+  if (has_fp && gq) wemu::launch(grid, [&] { m4::smooth_bwd_wave<true, true>(*p, *saved, *up, *out, ws); });
+  else if (has_fp) wemu::launch(grid, [&] { m4::smooth_bwd_wave<true, false>(*p, *saved, *up, *out, ws); });
+  else if (gq) wemu::launch(grid, [&] { m4::smooth_bwd_wave<false, true>(*p, *saved, *up, *out, ws); });
+  else wemu::launch(grid, [&] { m4::smooth_bwd_wave<false, false>(*p, *saved, *up, *out, ws); });
+}
+
+void kvae_wemu_fwd_n16(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts) {
+  n16::Lds L;   // one wavefront at a time: the tile of the workgroup in flight
+  memset(&L, 0xFF, sizeof(L));
+  g_launches[2] += 1;
+  if (st->aux) wemu::launch((unsigned)p->B, [&] { n16::smooth_fwd_wave<true>(*p, *st, do_filter, do_rts, L); });
+  else wemu::launch((unsigned)p->B, [&] { n16::smooth_fwd_wave<false>(*p, *st, do_filter, do_rts, L); });
+}
+void kvae_wemu_bwd_n16(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                       const kvae_lgssm_input_grads *out, float *ws, int has_fp) {
+  n16::Lds L;
+  memset(&L, 0xFF, sizeof(L));
+  const bool gq = out->gQ.ptr != nullptr;
+  g_launches[3] += 1;
+  if (has_fp && gq) wemu::launch((unsigned)p->B, [&] { n16::smooth_bwd_wave<true, true>(*p, *saved, *up, *out, ws, L); });
+  else if (has_fp) wemu::launch((unsigned)p->B, [&] { n16::smooth_bwd_wave<true, false>(*p, *saved, *up, *out, ws, L); });
+  else if (gq) wemu::launch((unsigned)p->B, [&] { n16::smooth_bwd_wave<false, true>(*p, *saved, *up, *out, ws, L); });
+  else wemu::launch((unsigned)p->B, [&] { n16::smooth_bwd_wave<false, false>(*p, *saved, *up, *out, ws, L); });
+}
+}

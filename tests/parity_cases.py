@@ -237,7 +237,7 @@ def n4_generic_fallback(DEV):
     unaligned_fallback(DEV, 4, 4, 2, B=19, T=11)
 
 
-def n16_indefinite_q(DEV):
+def n16_indefinite_q(DEV, B=3, T=12):
     """(16,16,2) with a process noise that is NOT positive semi-definite (the reference's stability recipe does this at
     n = 4): predicted covariances go indefinite, the natural-order elimination of the smoother gain meets a non-positive
     pivot and the kernels must fall back to the partially pivoted one (getrf's pivot sequence, which is what the C
@@ -245,7 +245,7 @@ def n16_indefinite_q(DEV):
     from kvae.kalman.lgssm_ops import LgssmSmooth, Slots
     from oracle import c_oracle
     from oracle import torch_oracle as O
-    B, T, n, m, p = 3, 12, 16, 16, 2
+    n, m, p = 16, 16, 2
     g = torch.Generator().manual_seed(77)
     A = 0.6 * torch.eye(n) + 0.15 * torch.randn(n, n, generator=g)
     Bm = 0.1 * torch.randn(n, m, generator=g)

@@ -108,11 +108,13 @@ def test_train_step_gpu(name, kind):
 @pytest.mark.parametrize("B,T,n,m,p,K", [(256, 50, 4, 4, 2, 3), (7, 33, 4, 4, 2, 3), (5, 17, 3, 2, 1, 2),
                                          (3, 9, 8, 5, 3, 4), (64, 200, 16, 16, 2, 3), (1, 1, 4, 4, 2, 3),
                                          (2, 2, 16, 16, 2, 1), (512, 200, 16, 16, 2, 3), (8, 200, 16, 16, 2, 3),
-                                         (5, 1, 16, 16, 2, 2), (8192, 6, 4, 4, 2, 3)])
+                                         (5, 1, 16, 16, 2, 2), (8192, 6, 4, 4, 2, 3), (3, 2, 4, 4, 2, 3), (17, 3, 4, 4, 2, 2),
+                                         (2, 3, 16, 16, 2, 2)])
 def test_vs_oracle_random(B, T, n, m, p, K):
     """Values vs the C oracle at every size, incl. the FULL BASELINE configs[4] shard (512, 200, 16); gradients vs the
     torch oracle's autograd up to configs[1] size (256, 50, 4) and for n = 16 at (8, 200, 16).  (8192, 6, 4): many wavefronts of the sixteen-
-    sequences-per-wavefront n = 4 kernels, with a ragged last one in (7, 33, 4)."""
+    sequences-per-wavefront n = 4 kernels, with a ragged last one in (7, 33, 4).  T = 1, 2, 3: the tails of the sweeps' unrolled
+    loops (two operand sets at n = 4, three at n = 16, rotated by name)."""
     parity_cases.vs_oracle_random(DEV, B, T, n, m, p, K)
 
 

@@ -28,6 +28,14 @@ parity_cases.conv_edge_vs_torch("cpu", 2)
 parity_cases.enc_mid_vs_torch("cpu", 2, 8)
 parity_cases.dec_up_vs_torch("cpu", 2, 4)
 parity_cases.vae_heads_vs_torch("cpu", 5)
+# the product's wavefront-level kernels (lgssm_m4.h / lgssm_q4.h, lgssm_n16.h) on emulated wavefronts (hostsim/wave_emu.h):
+# ragged last wavefront (19 sequences, 16 per wavefront), the tails of the unrolled loops (T = 3, T = 1), 16-byte accesses
+lib = _native.lib_for(torch.zeros(1))
+lib.dll.kvae_hostsim_wave_emu(1)
+for dims in ((19, 3, 4, 4, 2, 3), (1, 1, 4, 4, 2, 2), (2, 3, 16, 16, 2, 2)):
+    parity_cases.vs_oracle_random("cpu", *dims)
+assert min(lib.dll.kvae_wemu_launches(i) for i in range(4)) > 0
+lib.dll.kvae_hostsim_wave_emu(0)
 print("ASAN-OK")
 """
 
