@@ -101,6 +101,8 @@ __device__ __forceinline__ f4 transpose(f4 X, Lds &L, int j, int g) {
   __syncthreads();
   return *reinterpret_cast<const f4 *>(&L.t[j * LD + 4 * g]);
 }
+// (The same two as X^T = X^T I on the matrix cores - four dependent 16x16x4 MFMAs, no LDS - were measured in the adjoint sweeps:
+// 752 -> 778 us at the configs[4] shard.  An LDS round trip costs fewer cycles of the wavefront than a 128-cycle MFMA chain.)
 __device__ __forceinline__ f4 symmetrise(f4 X, Lds &L, int j, int g) {
   const f4 Xt = transpose(X, L, j, g);
   return f4{0.5f * (X[0] + Xt[0]), 0.5f * (X[1] + Xt[1]), 0.5f * (X[2] + Xt[2]), 0.5f * (X[3] + Xt[3])};
@@ -204,6 +206,24 @@ __device__ __forceinline__ void read_rows(float (&m)[N], const Lds &L, int j) {
     m[4 * q] = v[0], m[4 * q + 1] = v[1], m[4 * q + 2] = v[2], m[4 * q + 3] = v[3];
   }
 }
+// X = Mat^{-1} RHS with row j of Mat in m0 (which stays intact for the pivoted repeat) and the rows of RHS on the lanes
+__device__ __forceinline__ f4 solve_rows(const float (&m0)[N], f4 rhs, int lane) {
+  const int j = lane & 15;
+  float m[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c) m[c] = m0[c];
+  f4 x = rhs;
+  float my_rinv = 0.0f;
+  bool bad = false;
+  gj_step_spd<0>(m, x, my_rinv, bad, j);
+  if (__builtin_expect(__any(bad), 0)) {                       // not positive definite: redo with row exchanges
+#pragma unroll
+    for (int c = 0; c < N; ++c) m[c] = m0[c];
+    x = rhs;
+    gj_step_piv<0>(m, x, my_rinv, j, lane);
+  }
+  return f4{x[0] * my_rinv, x[1] * my_rinv, x[2] * my_rinv, x[3] * my_rinv};
+}
 // X = (Xc^T)^{-1} RHS with Xc in C-layout (so Mat = Xc^T has its rows on the lanes after one LDS hop) and RHS rows on lanes
 __device__ __forceinline__ f4 solve_transposed(f4 Xc, f4 rhs, Lds &L, int lane) {
   const int j = lane & 15, g = lane >> 4;
@@ -212,16 +232,13 @@ __device__ __forceinline__ f4 solve_transposed(f4 Xc, f4 rhs, Lds &L, int lane) 
   __syncthreads();
   float m[N];
   read_rows(m, L, j);
-  f4 x = rhs;
-  float my_rinv = 0.0f;
-  bool bad = false;
-  gj_step_spd<0>(m, x, my_rinv, bad, j);
-  if (__builtin_expect(__any(bad), 0)) {                       // not positive definite: redo with row exchanges
-    read_rows(m, L, j);
-    x = rhs;
-    gj_step_piv<0>(m, x, my_rinv, j, lane);
-  }
-  return f4{x[0] * my_rinv, x[1] * my_rinv, x[2] * my_rinv, x[3] * my_rinv};
+  return solve_rows(m, rhs, lane);
+}
+// row j of a row-major 16 x 16 matrix, whole (the four row-groups read the same 64 bytes)
+struct Row16 { f4 q[4]; };
+__device__ __forceinline__ Row16 load_row16(const float *X, int j) {
+  const f4 *r = reinterpret_cast<const f4 *>(X + j * N);
+  return Row16{{r[0], r[1], r[2], r[3]}};
 }
 
 // ---- per-step operands ---------------------------------------------------------------------------------------------
@@ -477,6 +494,7 @@ __device__ __forceinline__ void rts_bwd_sweep(const kvae_lgssm_problem &P, const
   store_rows(gstack_at(G.gA, b, 0), zero4(), j, g);
   struct In {
     f4 Sf, Spc, Spt, Ac, Ss, Jc, Jt, uSs, uSf, uSp;
+    Row16 Spr;   // row j of Sig_p[t+1], whole: the matrix of the adjoint's solve, straight from memory instead of through LDS
     float mupL, musL, uMs, uMf, uMp;
   } s, nx;
   // running pointers of step t: Sig_f[t], (Sig_p, Sig_s, mu_p, mu_s, A, upstream)[t+1], J[t]
@@ -487,6 +505,7 @@ __device__ __forceinline__ void rts_bwd_sweep(const kvae_lgssm_problem &P, const
     o.Sf = load_rows(S.Sigmas_filt + q * NN, j, g);
     o.Spc = load_c(S.Sigmas_pred + (q + 1) * NN, j, g);
     o.Spt = load_rows(S.Sigmas_pred + (q + 1) * NN, j, g);
+    o.Spr = load_row16(S.Sigmas_pred + (q + 1) * NN, j);
     o.Ss = load_rows(S.Sigmas_smooth + (q + 1) * NN, j, g);
     o.Ac = load_c(pA, j, g);
     const float *J = S.aux + q * KV_AUX_N16 + N * P2 + P2 * P2;
@@ -520,7 +539,10 @@ __device__ __forceinline__ void rts_bwd_sweep(const kvae_lgssm_problem &P, const
     const float dmuL = s.musL - s.mupL;
     const f4 gJ = mtn(Y1t, D2, outer(gsmW, dmuL));                  // Y1 (D^T + D) + gsm dmu^T
     const float gdmL = mtv(s.Jc, gsmW);                             // J^T gsm
-    const f4 gRt = solve_transposed(s.Spt, gJ, L, lane);            // Sig_p gR = gJ^T ; C-layout of gR^T
+    float Sprow[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) Sprow[c] = s.Spr.q[c >> 2][c & 3];
+    const f4 gRt = solve_rows(Sprow, gJ, lane);                     // Sig_p gR = gJ^T ; C-layout of gR^T
     const f4 gRc = transpose(gRt, L, j, g);
     const f4 gWA = mtn(gRc, s.Ac);                                  // gR^T A[t+1]
     const f4 gP = mtn(s.Jc, gRt);                                   // J^T gR^T
