@@ -50,11 +50,25 @@ template <bool AUX>
 __global__ __launch_bounds__(64) void k_smooth_fwd_m4(kvae_lgssm_problem P, kvae_lgssm_states S, int do_filter, int do_rts) {
   m4::smooth_fwd_wave<AUX>(P, S, do_filter, do_rts);
 }
+template <bool AUX>
+__global__ __launch_bounds__(64) void k_gains_m4(kvae_lgssm_problem P, kvae_lgssm_states S) {
+  m4::gains_wave<AUX>(P, S);
+}
+template <bool AUX>
+static void launch_fwd_m4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts, hipStream_t s) {
+  const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
+  if (m4::kv_m4_split(*p, do_filter, do_rts)) {   // filter sweep | all gains at once | smoother sweep (lgssm_m4.h: gains_wave)
+    k_smooth_fwd_m4<AUX><<<grid, block, 0, s>>>(*p, *st, 1, 0);
+    k_gains_m4<AUX><<<dim3(m4::kv_m4_gain_grid(*p)), block, 0, s>>>(*p, *st);
+    k_smooth_fwd_m4<AUX><<<grid, block, 0, s>>>(*p, *st, 0, KV_M4_RTS_WITH_GAINS);
+    return;
+  }
+  k_smooth_fwd_m4<AUX><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
+}
 extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts,
                                    hipStream_t s) {
-  const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
-  if (st->aux) k_smooth_fwd_m4<true><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
-  else k_smooth_fwd_m4<false><<<grid, block, 0, s>>>(*p, *st, do_filter, do_rts);
+  if (st->aux) launch_fwd_m4<true>(p, st, do_filter, do_rts, s);
+  else launch_fwd_m4<false>(p, st, do_filter, do_rts, s);
 }
 
 template <bool HAS_FP, bool HAS_GQ>

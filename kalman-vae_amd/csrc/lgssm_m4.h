@@ -493,6 +493,8 @@ __device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P_, c
 // ---- the kernels' bodies (kvae_lgssm_n16.hip wraps them in __global__ functions; tests/hostsim runs them on emulated wavefronts):
 // sixteen sequences per wavefront, grid = ceil(B / 16); a ragged last wavefront recomputes (and re-stores, identically) the last
 // sequence: no branch
+// do_rts: 0 no smoother; 1 smoother; KV_M4_RTS_WITH_GAINS: smoother whose gains J_t are already in their slots (gains_wave)
+#define KV_M4_RTS_WITH_GAINS 2
 template <bool AUX>
 __device__ __forceinline__ void smooth_fwd_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, int do_filter, int do_rts) {
   const int lane = threadIdx.x & 63, i = lane & 3;
@@ -504,9 +506,39 @@ __device__ __forceinline__ void smooth_fwd_wave(const kvae_lgssm_problem &P_, co
     rts_sweep<AUX, true>(P_, S, b, i, lane);
   } else if (do_filter) {
     filter_sweep<AUX, false>(P_, S, b, i, lane);
+  } else if (do_rts == KV_M4_RTS_WITH_GAINS) {
+    rts_sweep<AUX, true>(P_, S, b, i, lane);
   } else if (do_rts) {
     rts_sweep<AUX, false>(P_, S, b, i, lane);
   }
+}
+// The smoother gains of ALL steps at once: J_t = Sig_f[t] A_{t+1}^T Sig_p[t+1]^{-1} depends on the filter's results only, so
+// between a filter-only sweep and a gains-present smoother sweep it is B (T - 1) independent 4x4 problems - sixteen per wavefront,
+// grid = ceil(B (T - 1) / 16) - instead of ~120 instructions inside every step of a T-deep dependent stream.  The launcher takes
+// this three-launch form while the batch is far below the chip's wave slots (kv_m4_split: the sweeps are then bound by the
+// length of their instruction stream); above that the single launch with the gain hoisted into the filter step moves fewer bytes.
+constexpr int KV_M4_SPLIT_MAX_B = 2048;
+inline bool kv_m4_split(const kvae_lgssm_problem &P_, int do_filter, int do_rts) {   // host side (launchers)
+  return do_filter && do_rts && P_.T >= 2 && P_.B <= KV_M4_SPLIT_MAX_B;
+}
+inline unsigned kv_m4_gain_grid(const kvae_lgssm_problem &P_) {
+  return (unsigned)(((int64_t)P_.B * (P_.T - 1) + 15) / 16);
+}
+template <bool AUX>
+__device__ __forceinline__ void gains_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S) {
+  const int lane = threadIdx.x & 63, i = lane & 3;
+  const int64_t items = (int64_t)P_.B * (P_.T - 1);
+  int64_t it = (int64_t)blockIdx.x * 16 + (lane >> 2);
+  it = it < items ? it : items - 1;      // a ragged last wavefront recomputes the last item
+  const int b = (int)(it / (P_.T - 1)), t = (int)(it - (int64_t)b * (P_.T - 1));
+  const int64_t q = (int64_t)b * P_.T + t;
+  const Mat A = q4::load_rows(stack_at(P_.A, b, t + 1), i), Sf = q4::load_rows(S.Sigmas_filt + q * 16, i);
+  const Mat Spt = load_cols(S.Sigmas_pred + (q + 1) * 16, i);
+  const Mat W = P(Sf, A);                                    // A Sig_f   (Sig_f symmetric)
+  bool bad;
+  Mat X = solve_natural(Spt, W, i, bad);                     // Sig_p^T J^T = A Sig_f  (kalman_filter.py:229)
+  if (__any(bad)) X = solve_pivoted(Spt, W, i, lane);
+  q4::store_rows(gain_slot<AUX>(S, q), P(X, q4::eye(i)), i);
 }
 template <bool HAS_FP, bool HAS_GQ>
 __device__ __forceinline__ void smooth_bwd_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,

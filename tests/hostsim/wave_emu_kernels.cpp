@@ -19,6 +19,19 @@ int kvae_wemu_launches(int which) { return which >= 0 && which < 4 ? g_launches[
 void kvae_wemu_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts) {
   const unsigned grid = (unsigned)((p->B + 15) / 16);
   g_launches[0] += 1;
+  if (m4::kv_m4_split(*p, do_filter, do_rts)) {   // as launch_fwd_m4 of kvae_lgssm_n16.hip: filter | all gains at once | smoother
+    const unsigned gg = m4::kv_m4_gain_grid(*p);
+    if (st->aux) {
+      wemu::launch(grid, [&] { m4::smooth_fwd_wave<true>(*p, *st, 1, 0); });
+      wemu::launch(gg, [&] { m4::gains_wave<true>(*p, *st); });
+      wemu::launch(grid, [&] { m4::smooth_fwd_wave<true>(*p, *st, 0, KV_M4_RTS_WITH_GAINS); });
+    } else {
+      wemu::launch(grid, [&] { m4::smooth_fwd_wave<false>(*p, *st, 1, 0); });
+      wemu::launch(gg, [&] { m4::gains_wave<false>(*p, *st); });
+      wemu::launch(grid, [&] { m4::smooth_fwd_wave<false>(*p, *st, 0, KV_M4_RTS_WITH_GAINS); });
+    }
+    return;
+  }
   if (st->aux) wemu::launch(grid, [&] { m4::smooth_fwd_wave<true>(*p, *st, do_filter, do_rts); });
   else wemu::launch(grid, [&] { m4::smooth_fwd_wave<false>(*p, *st, do_filter, do_rts); });
 }
