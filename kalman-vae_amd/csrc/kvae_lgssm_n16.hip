@@ -73,15 +73,31 @@ extern "C" void kvae_q4_launch_fwd(const kvae_lgssm_problem *p, const kvae_lgssm
 
 template <bool HAS_FP, bool HAS_GQ>
 __global__ __launch_bounds__(64) void k_smooth_bwd_m4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
-                                                      kvae_lgssm_input_grads G, float *ws) {
-  m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(P, S, U, G, ws);
+                                                      kvae_lgssm_input_grads G, float *ws, int part) {
+  m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(P, S, U, G, ws, part);
+}
+template <bool HAS_FP>
+__global__ __launch_bounds__(64) void k_rts_bwd_items_m4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_states U,
+                                                         kvae_lgssm_input_grads G, float *ws) {
+  m4::rts_bwd_items<HAS_FP>(P, S, U, G, ws);
+}
+template <bool HAS_FP, bool HAS_GQ>
+static void launch_bwd_m4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                          const kvae_lgssm_input_grads *out, float *ws, hipStream_t s) {
+  const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
+  if (m4::kv_m4_split_bwd(*p)) {   // the smoother adjoint's chain | its hand-off records, all steps at once | the filter's adjoint
+    k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_CHAIN);
+    k_rts_bwd_items_m4<HAS_FP><<<dim3(m4::kv_m4_gain_grid(*p)), block, 0, s>>>(*p, *saved, *up, *out, ws);
+    k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_FILTER);
+    return;
+  }
+  k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_ALL);
 }
 extern "C" void kvae_q4_launch_bwd(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                                    const kvae_lgssm_input_grads *out, float *ws, int has_fp, hipStream_t s) {
-  const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
   const bool gq = out->gQ.ptr != nullptr;
-  if (has_fp && gq) k_smooth_bwd_m4<true, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-  else if (has_fp) k_smooth_bwd_m4<true, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-  else if (gq) k_smooth_bwd_m4<false, true><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
-  else k_smooth_bwd_m4<false, false><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws);
+  if (has_fp && gq) launch_bwd_m4<true, true>(p, saved, up, out, ws, s);
+  else if (has_fp) launch_bwd_m4<true, false>(p, saved, up, out, ws, s);
+  else if (gq) launch_bwd_m4<false, true>(p, saved, up, out, ws, s);
+  else launch_bwd_m4<false, false>(p, saved, up, out, ws, s);
 }

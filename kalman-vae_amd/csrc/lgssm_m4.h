@@ -369,6 +369,106 @@ __device__ __forceinline__ void rts_bwd_sweep(const kvae_lgssm_problem &P_, cons
   wl[i] = (HAS_FP ? U.mus_filt[ql * 4 + i] : 0.0f) + gsm;
 }
 
+// ---- the smoother's adjoint in two parts, for batches far below the chip's wave slots (kv_m4_split_bwd) ------------------------------
+// Of the ~270 instructions of an rts_bwd_sweep step only ~60 are on the chain that step t + 1 waits for: the adjoint of the
+// smoothed belief travels gM -> Y1^T -> gD (three products).  Everything else - the solve for the adjoint of the gain, four more
+// products, all of the hand-off record - hangs off it and is B (T - 1) independent problems.  rts_bwd_chain runs the chain alone and
+// leaves (gM, gsm) of every step in two OUTPUT slots that are written later anyway (gA[t+1]: the smoother's share lands there;
+// gU[t]: written by the filter's adjoint); rts_bwd_items turns them into the hand-off records, sixteen (b, t) per wavefront.  Same
+// operations on the same operands as rts_bwd_sweep: the two forms produce the same bits.
+template <bool HAS_FP>
+__device__ __forceinline__ void rts_bwd_chain(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                                              const kvae_lgssm_input_grads &G, float *ws, int b, int i) {
+  constexpr int WS_REC = q4::WS_REC;
+  const int T = P_.T;
+  const int64_t bT = (int64_t)b * T;
+  float *w = ws + bT * WS_REC;
+  float gsm = U.mus_smooth[bT * 4 + i];
+  Mat gsS = q4::load_rows(U.Sigmas_smooth + bT * 16, i), gsSt = load_cols(U.Sigmas_smooth + bT * 16, i);
+  w[4 + 16 + i] = HAS_FP ? U.mus_pred[bT * 4 + i] : 0.0f;
+  q4::store_rows(w + 4 + 16 + 4, HAS_FP ? q4::load_rows(U.Sigmas_pred + bT * 16, i) : q4::zero(), i);
+  q4::store_rows(gstack_at(G.gA, b, 0), q4::zero(), i);
+  struct In { Mat Jt, uSs, uSst; float uMs; } s, nx;
+  int64_t q = bT;
+  auto load = [&](In &o) {
+    o.Jt = load_cols(S.aux + q * KV_AUX_N4 + 12, i);
+    o.uMs = U.mus_smooth[(q + 1) * 4 + i];
+    o.uSs = q4::load_rows(U.Sigmas_smooth + (q + 1) * 16, i);
+    o.uSst = load_cols(U.Sigmas_smooth + (q + 1) * 16, i);
+  };
+  if (T >= 2) load(s);
+  nx = s;
+  KV_Q4_DRAIN();
+  auto step = [&](int t, const In &s, In &nx) {
+    if (t + 2 < T) q += 1;
+    load(nx);
+    KV_Q4_FENCE();
+    const Mat gM = half_sum(gsS, gsSt);                               // sym(adjoint of Sig_s[t])
+    q4::store_rows(gstack_at(G.gA, b, t + 1), gM, i);                 // parked for rts_bwd_items
+    G.gU[(bT + t) * 4 + i] = gsm;
+    const Mat Y1t = P(gM, s.Jt);                                      // (gM J)^T
+    const Mat gD = P(Y1t, s.Jt), gDt = P(s.Jt, Y1t);                  // J^T (gM J) and its transpose
+    const float gdm = dot(s.Jt, spread(gsm), 0.0f);                   // J^T gsm
+    gsS = q4::add(s.uSs, gD);
+    gsSt = q4::add(s.uSst, gDt);
+    gsm = s.uMs + gdm;
+  };
+  int t = 0;
+  for (; t + 2 < T; t += 2) {
+    step(t, s, nx);
+    step(t + 1, nx, s);
+  }
+  if (t + 1 < T) step(t, s, nx);
+  float *wl = w + (int64_t)(T - 1) * WS_REC;
+  const int64_t ql = bT + T - 1;
+  q4::store_rows(wl + 4, q4::add(HAS_FP ? q4::load_rows(U.Sigmas_filt + ql * 16, i) : q4::zero(), gsS), i);
+  wl[i] = (HAS_FP ? U.mus_filt[ql * 4 + i] : 0.0f) + gsm;
+}
+
+template <bool HAS_FP>
+__device__ __forceinline__ void rts_bwd_items(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
+                                              const kvae_lgssm_input_grads &G, float *ws) {
+  constexpr int WS_REC = q4::WS_REC;
+  const int lane = threadIdx.x & 63, i = lane & 3;
+  const int64_t items = (int64_t)P_.B * (P_.T - 1);
+  int64_t it = (int64_t)blockIdx.x * 16 + (lane >> 2);
+  it = it < items ? it : items - 1;      // a ragged last wavefront recomputes the last item
+  const int b = (int)(it / (P_.T - 1)), t = (int)(it - (int64_t)b * (P_.T - 1));
+  const int64_t q = (int64_t)b * P_.T + t;
+  float *wt = ws + q * WS_REC;
+  float *gA1 = gstack_at(G.gA, b, t + 1);
+  const Mat gM = q4::load_rows(gA1, i);
+  const float gsm = G.gU[q * 4 + i];
+  const Mat Jt = load_cols(S.aux + q * KV_AUX_N4 + 12, i), Sf = q4::load_rows(S.Sigmas_filt + q * 16, i);
+  const Mat Sp = q4::load_rows(S.Sigmas_pred + (q + 1) * 16, i), Spt = load_cols(S.Sigmas_pred + (q + 1) * 16, i);
+  const Mat Ss = q4::load_rows(S.Sigmas_smooth + (q + 1) * 16, i), At = load_cols(stack_at(P_.A, b, t + 1), i);
+  const float dmu = S.mus_smooth[(q + 1) * 4 + i] - S.mus_pred[(q + 1) * 4 + i];
+  const Mat uSf = HAS_FP ? q4::load_rows(U.Sigmas_filt + q * 16, i) : q4::zero();
+  const Mat uSp = HAS_FP ? q4::load_rows(U.Sigmas_pred + (q + 1) * 16, i) : q4::zero();
+  const float uMf = HAS_FP ? U.mus_filt[q * 4 + i] : 0.0f, uMp = HAS_FP ? U.mus_pred[(q + 1) * 4 + i] : 0.0f;
+  const Mat D2 = q4::add(q4::sub(Ss, Sp), q4::sub(Ss, Spt));          // D + D^T, D = Sig_s[t+1] - Sig_p[t+1]: symmetric
+  const Vec4 gsmv = spread(gsm);
+  const Mat Y1 = P(Jt, gM), Y1t = P(gM, Jt);                          // gM J and its transpose
+  Mat O;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) O.c[c] = dmu * gsmv.c[c];
+  const Mat gJt = P(Y1, D2, O);                                       // (Y1 (D^T + D) + gsm dmu^T)^T
+  const Mat gD = P(Y1t, Jt);                                          // J^T Y1
+  const float gdm = dot(Jt, gsmv, 0.0f);                              // J^T gsm
+  bool bad;
+  Mat gR = solve_natural(Sp, gJt, i, bad);                            // Sig_p gR = gJ^T
+  if (__any(bad)) gR = solve_pivoted(Sp, gJt, i, lane);
+  const Mat gRt = P(gR, q4::eye(i));
+  const Mat gWA = P(At, gRt);                                         // gR^T A[t+1]
+  const Mat gP = P(gR, Jt);                                           // J^T gR^T
+  const Mat gAs = P(Sf, gR);                                          // gR Sig_f: the smoother's share of gA[t+1]
+  q4::store_rows(wt + 4, q4::add(q4::add(uSf, gM), gWA), i);
+  q4::store_rows(wt + WS_REC + 4 + 16 + 4, q4::sub(q4::sub(uSp, gD), gP), i);
+  q4::store_rows(gA1, gAs, i);
+  wt[i] = uMf + gsm;
+  wt[WS_REC + 4 + 16 + i] = uMp - gdm;
+}
+
 template <bool HAS_GQ>
 __device__ __forceinline__ void filter_bwd_sweep(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S,
                                                  const kvae_lgssm_input_grads &G, const float *ws, int b, int i, int lane) {
@@ -540,16 +640,27 @@ __device__ __forceinline__ void gains_wave(const kvae_lgssm_problem &P_, const k
   if (__any(bad)) X = solve_pivoted(Spt, W, i, lane);
   q4::store_rows(gain_slot<AUX>(S, q), P(X, q4::eye(i)), i);
 }
+// part: KV_M4_BWD_ALL one launch; KV_M4_BWD_CHAIN the smoother adjoint's chain alone (then rts_bwd_items, then KV_M4_BWD_FILTER)
+#define KV_M4_BWD_ALL 0
+#define KV_M4_BWD_CHAIN 1
+#define KV_M4_BWD_FILTER 2
 template <bool HAS_FP, bool HAS_GQ>
 __device__ __forceinline__ void smooth_bwd_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
-                                                const kvae_lgssm_input_grads &G, float *ws) {
+                                                const kvae_lgssm_input_grads &G, float *ws, int part) {
   const int lane = threadIdx.x & 63, i = lane & 3;
   int b = blockIdx.x * 16 + (lane >> 2);
   b = b < P_.B ? b : P_.B - 1;
-  rts_bwd_sweep<HAS_FP>(P_, S, U, G, ws, b, i, lane);
-  __syncthreads();
-  filter_bwd_sweep<HAS_GQ>(P_, S, G, ws, b, i, lane);
+  if (part == KV_M4_BWD_CHAIN) {
+    rts_bwd_chain<HAS_FP>(P_, S, U, G, ws, b, i);
+  } else if (part == KV_M4_BWD_FILTER) {
+    filter_bwd_sweep<HAS_GQ>(P_, S, G, ws, b, i, lane);
+  } else {
+    rts_bwd_sweep<HAS_FP>(P_, S, U, G, ws, b, i, lane);
+    __syncthreads();
+    filter_bwd_sweep<HAS_GQ>(P_, S, G, ws, b, i, lane);
+  }
 }
+inline bool kv_m4_split_bwd(const kvae_lgssm_problem &P_) { return P_.T >= 2 && P_.B <= KV_M4_SPLIT_MAX_B; }   // host side
 
 }  // namespace m4
 }  // namespace kvae

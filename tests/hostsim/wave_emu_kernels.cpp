@@ -12,6 +12,18 @@ using namespace kvae;
 
 static int g_launches[4] = {0, 0, 0, 0};   // emulated launches so far: fwd n4, bwd n4, fwd n16, bwd n16 (tests assert they happened)
 
+template <bool HAS_FP, bool HAS_GQ>
+static void bwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
+                   const kvae_lgssm_input_grads *out, float *ws) {   // as launch_bwd_m4 of kvae_lgssm_n16.hip
+  const unsigned grid = (unsigned)((p->B + 15) / 16);
+  if (m4::kv_m4_split_bwd(*p)) {
+    wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_CHAIN); });
+    wemu::launch(m4::kv_m4_gain_grid(*p), [&] { m4::rts_bwd_items<HAS_FP>(*p, *saved, *up, *out, ws); });
+    wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_FILTER); });
+    return;
+  }
+  wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_ALL); });
+}
 extern "C" {
 
 int kvae_wemu_launches(int which) { return which >= 0 && which < 4 ? g_launches[which] : -1; }
@@ -37,13 +49,12 @@ void kvae_wemu_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, 
 }
 void kvae_wemu_bwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                       const kvae_lgssm_input_grads *out, float *ws, int has_fp) {
-  const unsigned grid = (unsigned)((p->B + 15) / 16);
   const bool gq = out->gQ.ptr != nullptr;
   g_launches[1] += 1;
-  if (has_fp && gq) wemu::launch(grid, [&] { m4::smooth_bwd_wave<true, true>(*p, *saved, *up, *out, ws); });
-  else if (has_fp) wemu::launch(grid, [&] { m4::smooth_bwd_wave<true, false>(*p, *saved, *up, *out, ws); });
-  else if (gq) wemu::launch(grid, [&] { m4::smooth_bwd_wave<false, true>(*p, *saved, *up, *out, ws); });
-  else wemu::launch(grid, [&] { m4::smooth_bwd_wave<false, false>(*p, *saved, *up, *out, ws); });
+  if (has_fp && gq) bwd_n4<true, true>(p, saved, up, out, ws);
+  else if (has_fp) bwd_n4<true, false>(p, saved, up, out, ws);
+  else if (gq) bwd_n4<false, true>(p, saved, up, out, ws);
+  else bwd_n4<false, false>(p, saved, up, out, ws);
 }
 
 void kvae_wemu_fwd_n16(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts) {
