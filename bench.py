@@ -362,8 +362,11 @@ def roofline_leg(args, cfg, model, x, n_prof_small=10):
         ach = chain[dom]["GBps"]
         n4 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (4, 4, 2)
         n16 = (cfg.z_dim, cfg.u_dim, cfg.a_dim) == (16, 16, 2)
-        kname = {"smooth_fwd": "k_smooth_fwd_m4" if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
-                 "smooth_bwd": "k_smooth_bwd_m4" if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
+        split = n4 and B <= 2048   # lgssm_m4.h: chain sweeps + per-step items as separate launches below KV_M4_SPLIT_MAX_B
+        kname = {"smooth_fwd": ("k_smooth_fwd_m4 (filter) + k_gains_m4 + k_smooth_fwd_m4 (smoother)" if split else "k_smooth_fwd_m4")
+                 if n4 else ("k_smooth_fwd_n16" if n16 else "k_smooth_fwd"),
+                 "smooth_bwd": ("k_smooth_bwd_m4 (two chain sweeps) + k_rts_bwd_items_m4 + k_filter_bwd_items_m4" if split
+                                else "k_smooth_bwd_m4") if n4 else ("k_smooth_bwd_n16" if n16 else "k_smooth_bwd"),
                  "elbo": "k_elbo_tpp(+probe)" if n4 else ("k_elbo4_n16 / k_elbo_n16 (+probe)" if n16 else "k_elbo(+probe)")}[dom]
         roofline = {"kernel": kname,
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -371,7 +374,8 @@ def roofline_leg(args, cfg, model, x, n_prof_small=10):
                     "bytes_per_unit": per_unit[dom], "units_per_launch": B * T, "avg_launch_us": chain[dom]["per_step_us"],
                     "note": "T-deep dependent recursion, " + ("sixteen sequences" if n4 else "one sequence") +
                             " per wavefront: latency-bound, not byte-bound, whenever the batch is far below the "
-                            "wave slots of the chip (" + ("B/16" if n4 else "B") + " wavefronts here)"}
+                            "wave slots of the chip (" + ("B/16" if n4 else "B") + " wavefronts here)" +
+                            ("; avg_launch_us is the sum of the launches named in 'kernel' (one C-ABI call)" if split else "")}
         # the kernel that dominates the STEP is outside the LGSSM path: the decoder 32->128 block on the f32 matrix cores
         up = chain.get("dec_up_fwd_s8")
         if up and (cfg.img_size, tuple(cfg.decoder_channels)) == (32, (32, 32, 32)):

@@ -81,14 +81,19 @@ __global__ __launch_bounds__(64) void k_rts_bwd_items_m4(kvae_lgssm_problem P, k
                                                          kvae_lgssm_input_grads G, float *ws) {
   m4::rts_bwd_items<HAS_FP>(P, S, U, G, ws);
 }
+__global__ __launch_bounds__(64) void k_filter_bwd_items_m4(kvae_lgssm_problem P, kvae_lgssm_states S, kvae_lgssm_input_grads G,
+                                                           const float *ws) {
+  m4::filter_bwd_items(P, S, G, ws);
+}
 template <bool HAS_FP, bool HAS_GQ>
 static void launch_bwd_m4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, const kvae_lgssm_states *up,
                           const kvae_lgssm_input_grads *out, float *ws, hipStream_t s) {
   const dim3 grid((unsigned)((p->B + 15) / 16)), block(64);
-  if (m4::kv_m4_split_bwd(*p)) {   // the smoother adjoint's chain | its hand-off records, all steps at once | the filter's adjoint
+  if (m4::kv_m4_split_bwd(*p)) {   // each adjoint's chain alone, then what hangs off it for all steps at once (lgssm_m4.h)
     k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_CHAIN);
     k_rts_bwd_items_m4<HAS_FP><<<dim3(m4::kv_m4_gain_grid(*p)), block, 0, s>>>(*p, *saved, *up, *out, ws);
-    k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_FILTER);
+    k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_FCHAIN);
+    k_filter_bwd_items_m4<<<dim3(m4::kv_m4_item_grid(*p)), block, 0, s>>>(*p, *saved, *out, ws);
     return;
   }
   k_smooth_bwd_m4<HAS_FP, HAS_GQ><<<grid, block, 0, s>>>(*p, *saved, *up, *out, ws, KV_M4_BWD_ALL);

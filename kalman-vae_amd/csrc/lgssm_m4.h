@@ -25,6 +25,8 @@
 // MFMA -> VALU / VALU -> MFMA hazards are the compiler's to handle; the pivoted solve (inline-asm DPP FMAs of lgssm_q4.h, the
 // rare path) is fenced by explicit wait states on both sides.  tools/m4_selftest.hip checks every primitive against plain loops.
 #pragma once
+#include <stdlib.h>
+
 #include "lgssm_q4.h"
 
 #if (!defined(KVAE_HOSTSIM) || defined(KVAE_WAVE_EMU)) && !defined(KV_TPP)   // KVAE_WAVE_EMU: tests/hostsim/wave_emu.h
@@ -618,12 +620,17 @@ __device__ __forceinline__ void smooth_fwd_wave(const kvae_lgssm_problem &P_, co
 // this three-launch form while the batch is far below the chip's wave slots (kv_m4_split: the sweeps are then bound by the
 // length of their instruction stream); above that the single launch with the gain hoisted into the filter step moves fewer bytes.
 constexpr int KV_M4_SPLIT_MAX_B = 2048;
-inline bool kv_m4_split(const kvae_lgssm_problem &P_, int do_filter, int do_rts) {   // host side (launchers)
-  return do_filter && do_rts && P_.T >= 2 && P_.B <= KV_M4_SPLIT_MAX_B;
+inline int kv_m4_split_max_b() {   // host side (launchers); KVAE_M4_SPLIT_MAX_B overrides (A/B runs; 0: always one launch)
+  static const int v = getenv("KVAE_M4_SPLIT_MAX_B") ? atoi(getenv("KVAE_M4_SPLIT_MAX_B")) : KV_M4_SPLIT_MAX_B;
+  return v;
+}
+inline bool kv_m4_split(const kvae_lgssm_problem &P_, int do_filter, int do_rts) {
+  return do_filter && do_rts && P_.T >= 2 && P_.B <= kv_m4_split_max_b();
 }
 inline unsigned kv_m4_gain_grid(const kvae_lgssm_problem &P_) {
   return (unsigned)(((int64_t)P_.B * (P_.T - 1) + 15) / 16);
 }
+inline unsigned kv_m4_item_grid(const kvae_lgssm_problem &P_) { return (unsigned)(((int64_t)P_.B * P_.T + 15) / 16); }
 template <bool AUX>
 __device__ __forceinline__ void gains_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S) {
   const int lane = threadIdx.x & 63, i = lane & 3;
@@ -640,10 +647,173 @@ __device__ __forceinline__ void gains_wave(const kvae_lgssm_problem &P_, const k
   if (__any(bad)) X = solve_pivoted(Spt, W, i, lane);
   q4::store_rows(gain_slot<AUX>(S, q), P(X, q4::eye(i)), i);
 }
-// part: KV_M4_BWD_ALL one launch; KV_M4_BWD_CHAIN the smoother adjoint's chain alone (then rts_bwd_items, then KV_M4_BWD_FILTER)
+// ---- the filter's adjoint in two parts (same idea, same gate) -----------------------------------------------------------------------
+// On the chain of filter_bwd_sweep: the adjoint of the filtered belief through the Joseph update and the gain (G -> X1 -> gIKC ->
+// gK -> Z -> g Sig_p) and back through the prediction (g Sig_p -> gSp A -> A^T (gSp A)).  Off it: gC, gY, gA, gB, gU - a third
+// of the instructions and nearly half of the products.  filter_bwd_chain leaves what those need in the hand-off record of the
+// step it has just consumed ([ gmu | Gm | gmp | Z ]) and parks g Sig_p in the gB slot; filter_bwd_items reads them back for all
+// (b, t) at once.  Same operations on the same operands as filter_bwd_sweep.
+template <bool HAS_GQ>
+__device__ __forceinline__ void filter_bwd_chain(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S,
+                                                 const kvae_lgssm_input_grads &G, float *ws, int b, int i) {
+  constexpr int WS_REC = q4::WS_REC;
+  const int T = P_.T;
+  const int64_t bT = (int64_t)b * T;
+  const float R00 = P_.R[0], R01 = P_.R[1], R10 = P_.R[2], R11 = P_.R[3];
+  const Mat I4 = q4::eye(i);
+  struct In {
+    Mat At, Sp, Spt, wSf, wSft, wSp;
+    Vec4 C0, C1;
+    float Cl0, Cl1, mk, mup, wmf, wmp;
+    f2 y, ku;
+    f4 Sv;
+  } s, nx;
+  q4::StepPtr ptr;
+  ptr.init(P_, b, T - 1);
+  int t_ld = T - 1;
+  auto load = [&](In &o) {
+    const int64_t q = bT + t_ld;
+    o.At = load_cols(ptr.A, i);
+    o.C0 = load_vec(ptr.C), o.C1 = load_vec(ptr.C + 4);
+    o.Cl0 = ptr.C[i], o.Cl1 = ptr.C[4 + i];
+    o.y = *reinterpret_cast<const f2 *>(ptr.Y);
+    o.mk = *ptr.mk;
+    o.Sp = q4::load_rows(S.Sigmas_pred + q * 16, i), o.Spt = load_cols(S.Sigmas_pred + q * 16, i);
+    o.mup = S.mus_pred[q * 4 + i];
+    const float *ax = S.aux + q * KV_AUX_N4;
+    o.ku = *reinterpret_cast<const f2 *>(ax + 2 * i);
+    o.Sv = *reinterpret_cast<const f4 *>(ax + 8);
+    const float *w = ws + q * WS_REC;
+    o.wmf = w[i];
+    o.wSf = q4::load_rows(w + 4, i), o.wSft = load_cols(w + 4, i);
+    o.wmp = w[4 + 16 + i];
+    o.wSp = q4::load_rows(w + 4 + 16 + 4, i);
+  };
+  load(s);
+  nx = s;
+  KV_Q4_DRAIN();
+  float gmu = 0.0f;
+  Mat gSig = q4::zero(), gSigt = q4::zero();
+  auto step = [&](int t, const In &s, In &nx) {
+    if (t >= 1) t_ld = t - 1, ptr.step(-1);
+    load(nx);
+    KV_Q4_FENCE();
+    const int64_t q = bT + t;
+    const float mk = P_.mask ? s.mk : 1.0f;
+    gmu += s.wmf;
+    gSig = q4::add(gSig, s.wSf), gSigt = q4::add(gSigt, s.wSft);
+    const Mat Gm = half_sum(gSig, gSigt);
+    const float k0 = mk * s.ku[0], k1 = mk * s.ku[1];
+    const Vec4 k0v = spread(k0), k1v = spread(k1);
+    const Mat Mt = outer2(-k0, s.Cl0, -k1, s.Cl1, I4);                // (I - K C)^T = I - C0 k0^T - C1 k1^T
+    const float gr0 = q4::qsum(k0 * gmu), gr1 = q4::qsum(k1 * gmu);   // gr = K^T gmu
+    const float r0 = s.y[0] - q4::qsum(s.Cl0 * s.mup), r1 = s.y[1] - q4::qsum(s.Cl1 * s.mup);
+    const Mat Sp2 = q4::add(s.Sp, s.Spt);                             // symmetric
+    const Mat X1 = P(Mt, Gm), X1t = P(Gm, Mt);                        // G (I - K C) and its transpose
+    const Mat gIKC = P(Sp2, X1);                                      // X1 (Sig_p^T + Sig_p)
+    Mat gSp = P(X1t, Mt, s.wSp);                                      // (I - K C)^T X1 + handed-off
+    const float GK0 = dot(Gm, k0v, 0.0f), GK1 = dot(Gm, k1v, 0.0f);
+    const float gK0 = GK0 * (R00 + R00) + GK1 * (R01 + R10) - dot(gIKC, s.C0, 0.0f) + gmu * r0;
+    const float gK1 = GK0 * (R10 + R01) + GK1 * (R11 + R11) - dot(gIKC, s.C1, 0.0f) + gmu * r1;
+    const q4::Inv2 F = q4::factor2(s.Sv[0], s.Sv[1], s.Sv[3]);
+    float z0, z1;
+    q4::solve2(F, mk * gK0, mk * gK1, z0, z1);                        // Z = S^{-T} (mask gK^T): column i on lane i
+    const float zk00 = q4::qsum(z0 * s.ku[0]), zk01 = q4::qsum(z0 * s.ku[1]), zk10 = q4::qsum(z1 * s.ku[0]),
+                zk11 = q4::qsum(z1 * s.ku[1]);
+    const float h00 = -0.5f * (zk00 + zk00), h01 = -0.5f * (zk01 + zk10), h11 = -0.5f * (zk11 + zk11);
+    const float gCP0 = h00 * s.Cl0 + h01 * s.Cl1, gCP1 = h01 * s.Cl0 + h11 * s.Cl1;   // gCP = gS0 C (lane j: column j)
+    gSp = outer2(gCP0, s.Cl0, gCP1, s.Cl1, outer2(s.Cl0, z0, s.Cl1, z1, gSp));   // gSp += Z^T C + C^T gCP
+    const float gmp = gmu + s.wmp - (s.Cl0 * gr0 + s.Cl1 * gr1);      // gmp = gmu + handed-off - C^T gr
+    // for filter_bwd_items: [ gmu | Gm | gmp | Z ] over the record this step has consumed, g Sig_p in the gB slot
+    float *w = ws + q * WS_REC;
+    w[i] = gmu;
+    q4::store_rows(w + 4, Gm, i);
+    w[4 + 16 + i] = gmp;
+    w[4 + 16 + 4 + i] = z0, w[4 + 16 + 8 + i] = z1;
+    q4::store_rows(gstack_at(G.gB, b, t), gSp, i);
+    if constexpr (HAS_GQ) q4::store_rows(gstack_at(G.gQ, b, t), gSp, i);
+    const Mat gAS = P(s.At, gSp), gASt = P(gSp, s.At);                // gSp A and its transpose
+    gSig = P(gASt, s.At), gSigt = P(s.At, gASt);                      // A^T (gSp A) and its transpose
+    gmu = dot(s.At, spread(gmp), 0.0f);                               // A^T gmp
+    (void)gAS;
+  };
+  int t = T - 1;
+  for (; t >= 1; t -= 2) {
+    step(t, s, nx);
+    step(t - 1, nx, s);
+  }
+  if (t >= 0) step(t, s, nx);
+  if (G.g_mu0) G.g_mu0[(int64_t)b * 4 + i] = gmu;
+  if (G.g_Sigma0) q4::store_rows(G.g_Sigma0 + (int64_t)b * 16, gSig, i);
+}
+
+__device__ __forceinline__ void filter_bwd_items(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S,
+                                                 const kvae_lgssm_input_grads &G, const float *ws) {
+  constexpr int WS_REC = q4::WS_REC;
+  const int lane = threadIdx.x & 63, i = lane & 3;
+  const int64_t items = (int64_t)P_.B * P_.T;
+  int64_t q = (int64_t)blockIdx.x * 16 + (lane >> 2);
+  q = q < items ? q : items - 1;         // a ragged last wavefront recomputes the last item
+  const int b = (int)(q / P_.T), t = (int)(q - (int64_t)b * P_.T);
+  const Mat I4 = q4::eye(i);
+  q4::StepPtr ptr;
+  ptr.init(P_, b, t);
+  const Mat A = q4::load_rows(ptr.A, i), At = load_cols(ptr.A, i), Bt = load_cols(ptr.Bm, i);
+  const Vec4 C0 = load_vec(ptr.C), C1 = load_vec(ptr.C + 4), u = load_vec(ptr.U);
+  const float Cl0 = ptr.C[i], Cl1 = ptr.C[4 + i];
+  const float mk = P_.mask ? *ptr.mk : 1.0f;
+  const float *pS = t > 0 ? S.Sigmas_filt + (q - 1) * 16 : P_.Sigma0 + (int64_t)b * P_.Sigma0_sb;
+  const float *pm = t > 0 ? S.mus_filt + (q - 1) * 4 : P_.mu0 + (int64_t)b * P_.mu0_sb;
+  const Mat Sig = q4::load_rows(pS, i), Sigt = load_cols(pS, i);
+  const Vec4 mu = load_vec(pm);
+  const Mat Sp = q4::load_rows(S.Sigmas_pred + q * 16, i), Spt = load_cols(S.Sigmas_pred + q * 16, i);
+  const float mup = S.mus_pred[q * 4 + i];
+  const f2 ku = *reinterpret_cast<const f2 *>(S.aux + q * KV_AUX_N4 + 2 * i);
+  const float *w = ws + q * WS_REC;
+  const float gmu = w[i], gmp = w[4 + 16 + i], z0 = w[4 + 16 + 4 + i], z1 = w[4 + 16 + 8 + i];
+  const Mat Gm = q4::load_rows(w + 4, i);
+  float *gBo = gstack_at(G.gB, b, t), *gAo = gstack_at(G.gA, b, t);
+  const Mat gSp = q4::load_rows(gBo, i), gAs = q4::load_rows(gAo, i);
+  const float k0 = mk * ku[0], k1 = mk * ku[1];
+  const Vec4 k0v = spread(k0), k1v = spread(k1);
+  const Mat Mt = outer2(-k0, Cl0, -k1, Cl1, I4);
+  const float gr0 = q4::qsum(k0 * gmu), gr1 = q4::qsum(k1 * gmu);     // gr = K^T gmu
+  const Mat Sp2 = q4::add(Sp, Spt);
+  const Mat X1 = P(Mt, Gm);
+  const Mat gIKCt = P(X1, Sp2);                                       // (X1 (Sig_p^T + Sig_p))^T
+  const float zk00 = q4::qsum(z0 * ku[0]), zk01 = q4::qsum(z0 * ku[1]), zk10 = q4::qsum(z1 * ku[0]), zk11 = q4::qsum(z1 * ku[1]);
+  const float h00 = -0.5f * (zk00 + zk00), h01 = -0.5f * (zk01 + zk10), h11 = -0.5f * (zk11 + zk11);
+  const float gCP0 = h00 * Cl0 + h01 * Cl1, gCP1 = h01 * Cl0 + h11 * Cl1;
+  const Vec4 gCP0v = spread(gCP0), gCP1v = spread(gCP1);
+  // gC = -K^T gIKC + Z Sig_p + gS0 (C Sig_p) + gCP Sig_p^T - gr mu_p^T    (lane j: column j)
+  const float cp0 = dot(Spt, C0, 0.0f), cp1 = dot(Spt, C1, 0.0f);
+  const float gC0 = -dot(gIKCt, k0v, 0.0f) + dot(Spt, spread(z0), 0.0f) + (h00 * cp0 + h01 * cp1) + dot(Sp, gCP0v, 0.0f) - gr0 * mup;
+  const float gC1 = -dot(gIKCt, k1v, 0.0f) + dot(Spt, spread(z1), 0.0f) + (h01 * cp0 + h11 * cp1) + dot(Sp, gCP1v, 0.0f) - gr1 * mup;
+  float *gCo = gstack_at(G.gC, b, t);
+  gCo[i] = gC0, gCo[4 + i] = gC1;
+  G.gY[q * 2 + (i & 1)] = (i & 1) ? gr1 : gr0;
+  // gA[t] = smoother share + gSp^T (A Sig) + (gSp A) Sig^T + gmp mu^T
+  const Mat gSpt = P(gSp, I4);
+  const Mat ASt = P(A, Sigt);                                         // (A Sig)^T
+  const Mat gAS = P(At, gSp);                                         // gSp A
+  Mat gA;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gA.c[c] = fmaf(gmp, mu.c[c], gAs.c[c]);
+  gA = P(Sig, gAS, gA);                                               // + (gSp A) Sig^T
+  gA = P(ASt, gSpt, gA);                                              // + gSp^T (A Sig)
+  q4::store_rows(gAo, gA, i);
+  Mat gB;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) gB.c[c] = gmp * u.c[c];
+  q4::store_rows(gBo, gB, i);
+  G.gU[q * 4 + i] = dot(Bt, spread(gmp), 0.0f);                       // B^T gmp
+}
+
+// part: KV_M4_BWD_ALL one launch; split form: KV_M4_BWD_CHAIN (the smoother adjoint's chain), rts_bwd_items, KV_M4_BWD_FCHAIN (the
+// filter adjoint's chain), filter_bwd_items
 #define KV_M4_BWD_ALL 0
 #define KV_M4_BWD_CHAIN 1
-#define KV_M4_BWD_FILTER 2
+#define KV_M4_BWD_FCHAIN 2
 template <bool HAS_FP, bool HAS_GQ>
 __device__ __forceinline__ void smooth_bwd_wave(const kvae_lgssm_problem &P_, const kvae_lgssm_states &S, const kvae_lgssm_states &U,
                                                 const kvae_lgssm_input_grads &G, float *ws, int part) {
@@ -652,15 +822,15 @@ __device__ __forceinline__ void smooth_bwd_wave(const kvae_lgssm_problem &P_, co
   b = b < P_.B ? b : P_.B - 1;
   if (part == KV_M4_BWD_CHAIN) {
     rts_bwd_chain<HAS_FP>(P_, S, U, G, ws, b, i);
-  } else if (part == KV_M4_BWD_FILTER) {
-    filter_bwd_sweep<HAS_GQ>(P_, S, G, ws, b, i, lane);
+  } else if (part == KV_M4_BWD_FCHAIN) {
+    filter_bwd_chain<HAS_GQ>(P_, S, G, ws, b, i);
   } else {
     rts_bwd_sweep<HAS_FP>(P_, S, U, G, ws, b, i, lane);
     __syncthreads();
     filter_bwd_sweep<HAS_GQ>(P_, S, G, ws, b, i, lane);
   }
 }
-inline bool kv_m4_split_bwd(const kvae_lgssm_problem &P_) { return P_.T >= 2 && P_.B <= KV_M4_SPLIT_MAX_B; }   // host side
+inline bool kv_m4_split_bwd(const kvae_lgssm_problem &P_) { return P_.T >= 2 && P_.B <= kv_m4_split_max_b(); }   // host side
 
 }  // namespace m4
 }  // namespace kvae

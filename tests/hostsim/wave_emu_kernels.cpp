@@ -19,7 +19,8 @@ static void bwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, 
   if (m4::kv_m4_split_bwd(*p)) {
     wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_CHAIN); });
     wemu::launch(m4::kv_m4_gain_grid(*p), [&] { m4::rts_bwd_items<HAS_FP>(*p, *saved, *up, *out, ws); });
-    wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_FILTER); });
+    wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_FCHAIN); });
+    wemu::launch(m4::kv_m4_item_grid(*p), [&] { m4::filter_bwd_items(*p, *saved, *out, ws); });
     return;
   }
   wemu::launch(grid, [&] { m4::smooth_bwd_wave<HAS_FP, HAS_GQ>(*p, *saved, *up, *out, ws, KV_M4_BWD_ALL); });

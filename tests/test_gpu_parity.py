@@ -424,7 +424,7 @@ def test_explicit_ones_mask_equals_no_mask():
             assert rel_err(y.cpu(), x.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("env", [{"KVAE_WINO": "0"}, {"KVAE_Q4": "0"}, {"KVAE_N16": "0"}])
+@pytest.mark.parametrize("env", [{"KVAE_WINO": "0"}, {"KVAE_Q4": "0"}, {"KVAE_N16": "0"}, {"KVAE_M4_SPLIT_MAX_B": "0"}])
 def test_ab_switches_select_working_kernels(env):
     """The fault-isolation switches that remain (read once per process: direct instead of Winograd decoder blocks, one wavefront
     per sequence at n = 4, run-time-dimension kernels at n = 16 - each also the product's path for operands the specialised

@@ -8,7 +8,7 @@ for r in csv.DictReader(open(f)):
     if names and r["Counter_Name"] not in names:
         continue
     k = r["Kernel_Name"].split("(")[0][:60]
-    if not any(t in k for t in ("k_smooth", "k_elbo", "k_alpha", "k_filter_alpha", "k_mix", "k_lstm", "k_regime", "k_vae", "k_enc_", "k_dec_", "k_colsum", "k_latent", "k_gru")):
+    if not any(t in k for t in ("k_smooth", "k_gains", "k_rts_bwd_items", "k_filter_bwd_items", "k_elbo", "k_alpha", "k_filter_alpha", "k_mix", "k_lstm", "k_regime", "k_vae", "k_enc_", "k_dec_", "k_colsum", "k_latent", "k_gru")):
         continue
     a = acc[k][r["Counter_Name"]]
     a[0] += 1

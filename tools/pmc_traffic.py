@@ -12,16 +12,19 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-GROUPS = {"smooth_fwd": ("k_smooth_fwd",), "smooth_bwd": ("k_smooth_bwd",), "elbo": ("k_elbo",),
+# an op of the n = 4 path below 2048 sequences is several launches (lgssm_m4.h): the sweeps' kernel twice + the per-step items
+GROUPS = {"smooth_fwd": ("k_smooth_fwd", "k_gains_m4"), "smooth_bwd": ("k_smooth_bwd", "k_rts_bwd_items", "k_filter_bwd_items"),
+          "elbo": ("k_elbo",),
           "lstm_fwd": ("k_lstm_fwd",), "lstm_bwd": ("k_lstm_bwd",)}
 
 
 def parse(path):
     out, cur = {}, None
     for line in path.read_text().splitlines():
-        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)\s+\(avg over (\d+) launches\)", line)
         if m and cur:
             out.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+            out[cur]["launches"] = int(m.group(3))
         elif line and not line.startswith(" "):
             cur = line.strip()
     return out
@@ -29,13 +32,14 @@ def parse(path):
 
 def traffic(path, fetch_x2):
     per = parse(path)
+    iters = min(c["launches"] for c in per.values())   # every kernel of the chain runs at least once per iteration of the tool
     res = {}
     for name, keys in GROUPS.items():
         tot = 0.0
         for kern, c in per.items():
             if any(k in kern for k in keys):
                 x = 2.0 if any(t in kern for t in fetch_x2) else 1.0
-                tot += x * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)
+                tot += (x * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * (c["launches"] / iters)   # launches per op
         res[name] = int(round(tot * 1024))
     return res
 
