@@ -153,14 +153,19 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const
   const Mat I4 = q4::eye(i);
   q4::StepPtr ptr;
   ptr.init(P_, b, 0);
-  StepIn s, nx;
-  load_step(ptr, i, s);
-  nx = s;
+  // Operands TWO steps ahead: a chain step is ~0.5 us, less than an HBM miss under load (SQ counters of the one-step version,
+  // profiles/r03_m4_{fwd,bwd}_sq.txt: 18-23 % of every sweep in s_waitcnt).  Three operand sets that rotate by NAME - the caller
+  // is unrolled three times - because a register copy of a prefetched value waits for its load.
+  StepIn s0, s1, s2;
+  load_step(ptr, i, s0);
+  if (T > 1) ptr.step(1);
+  load_step(ptr, i, s1);
+  s2 = s1;
   KV_Q4_DRAIN();
-  // one step: operands in `s`, the next step's fetched into `nx` (the caller alternates the two: no register copies)
-  auto step = [&](int t, const StepIn &s, StepIn &nx) {
-    if (t + 1 < T) ptr.step(1);
-    load_step(ptr, i, nx);                                   // unconditional prefetch, pinned above this step's stores
+  // one step: operands in `s`, those of step t + 2 fetched into `far`
+  auto step = [&](int t, const StepIn &s, StepIn &far) {
+    if (t + 2 < T) ptr.step(1);
+    load_step(ptr, i, far);                                  // unconditional prefetch, pinned above this step's stores
     KV_Q4_FENCE();
     const int64_t q = bT + t;
     // predict (kalman_filter.py:65-67)
@@ -210,11 +215,13 @@ __device__ __forceinline__ void filter_sweep(const kvae_lgssm_problem &P_, const
     }
   };
   int t = 0;
-  for (; t + 1 < T; t += 2) {
-    step(t, s, nx);
-    step(t + 1, nx, s);
+  for (; t + 2 < T; t += 3) {
+    step(t, s0, s2);
+    step(t + 1, s1, s0);
+    step(t + 2, s2, s1);
   }
-  if (t < T) step(t, s, nx);
+  if (t < T) step(t, s0, s2);
+  if (t + 1 < T) step(t + 1, s1, s0);
 }
 
 template <bool AUX, bool HAVE_J>
@@ -225,7 +232,7 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kv
   float mus = S.mus_filt[(bT + T - 1) * 4 + i];
   q4::store_rows(S.Sigmas_smooth + (bT + T - 1) * 16, SigS, i);
   S.mus_smooth[(bT + T - 1) * 4 + i] = mus;
-  struct In { Mat Sf, Sp, Spt, A; float muf, mup; } s, nx;   // A: the gain J_t itself when the filter sweep left it (HAVE_J)
+  struct In { Mat Sf, Sp, Spt, A; float muf, mup; } s0, s1, s2;   // A: the gain J_t itself when the filter sweep left it (HAVE_J)
   int64_t q = bT + (T >= 2 ? T - 2 : 0);
   const float *pA = stack_at(P_.A, b, T >= 2 ? T - 1 : 0);
   const int64_t sA = P_.A.st;
@@ -237,14 +244,19 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kv
     o.muf = S.mus_filt[q * 4 + i];
     o.mup = S.mus_pred[(q + 1) * 4 + i];
   };
-  if (T >= 2) load(s);
-  nx = s;
+  if (T >= 2) load(s0);
+  s1 = s0;
+  if (T >= 3) {
+    q -= 1, pA -= sA;
+    load(s1);
+  }
+  s2 = s1;
   KV_Q4_DRAIN();
   const Mat I4 = q4::eye(i);
-  auto step = [&](int t, const In &s, In &nx) {
+  auto step = [&](int t, const In &s, In &far) {              // operands two steps ahead, rotated by name: see filter_sweep
     const int64_t qt = bT + t;
-    if (t >= 1) q -= 1, pA -= sA;
-    load(nx);
+    if (t >= 2) q -= 1, pA -= sA;
+    load(far);
     KV_Q4_FENCE();
     Mat J = s.A;
     if constexpr (!HAVE_J) {
@@ -266,11 +278,13 @@ __device__ __forceinline__ void rts_sweep(const kvae_lgssm_problem &P_, const kv
     S.mus_smooth[qt * 4 + i] = mus;
   };
   int t = T - 2;
-  for (; t >= 1; t -= 2) {
-    step(t, s, nx);
-    step(t - 1, nx, s);
+  for (; t >= 2; t -= 3) {
+    step(t, s0, s2);
+    step(t - 1, s1, s0);
+    step(t - 2, s2, s1);
   }
-  if (t >= 0) step(t, s, nx);
+  if (t >= 0) step(t, s0, s2);
+  if (t >= 1) step(t - 1, s1, s0);
 }
 
 
@@ -391,7 +405,7 @@ __device__ __forceinline__ void rts_bwd_chain(const kvae_lgssm_problem &P_, cons
   w[4 + 16 + i] = HAS_FP ? U.mus_pred[bT * 4 + i] : 0.0f;
   q4::store_rows(w + 4 + 16 + 4, HAS_FP ? q4::load_rows(U.Sigmas_pred + bT * 16, i) : q4::zero(), i);
   q4::store_rows(gstack_at(G.gA, b, 0), q4::zero(), i);
-  struct In { Mat Jt, uSs, uSst; float uMs; } s, nx;
+  struct In { Mat Jt, uSs, uSst; float uMs; } s0, s1, s2;
   int64_t q = bT;
   auto load = [&](In &o) {
     o.Jt = load_cols(S.aux + q * KV_AUX_N4 + 12, i);
@@ -399,12 +413,17 @@ __device__ __forceinline__ void rts_bwd_chain(const kvae_lgssm_problem &P_, cons
     o.uSs = q4::load_rows(U.Sigmas_smooth + (q + 1) * 16, i);
     o.uSst = load_cols(U.Sigmas_smooth + (q + 1) * 16, i);
   };
-  if (T >= 2) load(s);
-  nx = s;
+  if (T >= 2) load(s0);
+  s1 = s0;
+  if (T >= 3) {
+    q += 1;
+    load(s1);
+  }
+  s2 = s1;
   KV_Q4_DRAIN();
-  auto step = [&](int t, const In &s, In &nx) {
-    if (t + 2 < T) q += 1;
-    load(nx);
+  auto step = [&](int t, const In &s, In &far) {                      // operands two steps ahead, rotated by name: see filter_sweep
+    if (t + 3 < T) q += 1;
+    load(far);
     KV_Q4_FENCE();
     const Mat gM = half_sum(gsS, gsSt);                               // sym(adjoint of Sig_s[t])
     q4::store_rows(gstack_at(G.gA, b, t + 1), gM, i);                 // parked for rts_bwd_items
@@ -417,11 +436,13 @@ __device__ __forceinline__ void rts_bwd_chain(const kvae_lgssm_problem &P_, cons
     gsm = s.uMs + gdm;
   };
   int t = 0;
-  for (; t + 2 < T; t += 2) {
-    step(t, s, nx);
-    step(t + 1, nx, s);
+  for (; t + 3 < T; t += 3) {
+    step(t, s0, s2);
+    step(t + 1, s1, s0);
+    step(t + 2, s2, s1);
   }
-  if (t + 1 < T) step(t, s, nx);
+  if (t + 1 < T) step(t, s0, s2);
+  if (t + 2 < T) step(t + 1, s1, s0);
   float *wl = w + (int64_t)(T - 1) * WS_REC;
   const int64_t ql = bT + T - 1;
   q4::store_rows(wl + 4, q4::add(HAS_FP ? q4::load_rows(U.Sigmas_filt + ql * 16, i) : q4::zero(), gsS), i);
