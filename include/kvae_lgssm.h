@@ -95,9 +95,11 @@ int kvae_lgssm_filter_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_state
  * KalmanFilter.smooth (kalman_filter.py:204-237, 249-272). Reads filt/pred, writes smooth. */
 int kvae_lgssm_rts_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *io, void *stream);
 
-/* Filter + RTS in ONE launch, the whole T loop in-kernel: sixteen sequences per wavefront at (n,m,p) = (4,4,2), one sequence per
- * wavefront on the f32 matrix cores at (16,16,2) and in the run-time-dimension kernels otherwise.
- * Replaces KalmanFilter.smooth (kalman_filter.py:240-279). Writes all six stacks. */
+/* Filter + RTS in ONE call, the whole T loop in-kernel: sixteen sequences per wavefront at (n,m,p) = (4,4,2), one sequence per
+ * wavefront on the f32 matrix cores at (16,16,2) and in the run-time-dimension kernels otherwise.  One launch, except at (4,4,2)
+ * below 2048 sequences: filter sweep | all smoother gains at once | smoother sweep, three launches on `stream` (same results).
+ * Replaces KalmanFilter.smooth (kalman_filter.py:240-279). Writes all six stacks (and, if out->aux is NULL at (4,4,2), uses
+ * Sigmas_smooth as scratch for the gains before it holds the result). */
 int kvae_lgssm_smooth_fwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *out, void *stream);
 
 /* Kalman filter with the LSTM alpha-network stepped INSIDE the kernel (masked sequences: the network input of a
@@ -117,7 +119,9 @@ int kvae_lgssm_filter_alpha_lstm(const kvae_lgssm_problem *prob, const kvae_lgss
 /* Reverse-mode of kvae_lgssm_smooth_fwd (with_rts = 1) or kvae_lgssm_filter_fwd (with_rts = 0):
  * replaces what autograd records for kalman_filter.py:151-185, 257-272.  `saved` holds the forward
  * results; `up` holds upstream gradients of the six stacks (any pointer may be NULL = zero).
- * Scratch: ws [B,T,2*(n+n*n)] floats (adjoints handed from the smoother sweep to the filter sweep). */
+ * Scratch: ws [B,T,2*(n+n*n)] floats (adjoints handed from the smoother sweep to the filter sweep).  At (4,4,2) below 2048
+ * sequences the call is four launches (each adjoint's dependent chain, then what hangs off it for all steps at once); the output
+ * buffers gA, gB, gU hold intermediate values between them.  Outputs are complete when the call's last launch has run. */
 int kvae_lgssm_smooth_bwd(const kvae_lgssm_problem *prob, const kvae_lgssm_states *saved,
                           const kvae_lgssm_states *up, const kvae_lgssm_input_grads *out,
                           float *ws, int with_rts, void *stream);
