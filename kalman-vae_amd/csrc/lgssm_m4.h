@@ -642,9 +642,13 @@ __device__ __forceinline__ void smooth_fwd_wave(const kvae_lgssm_problem &P_, co
 // this three-launch form while the batch is far below the chip's wave slots (kv_m4_split: the sweeps are then bound by the
 // length of their instruction stream); above that the single launch with the gain hoisted into the filter step moves fewer bytes.
 constexpr int KV_M4_SPLIT_MAX_B = 2048;
+inline int &kv_m4_split_override() {   // < 0: none (tests/hostsim sets it to compare the two forms in one process)
+  static int v = -1;
+  return v;
+}
 inline int kv_m4_split_max_b() {   // host side (launchers); KVAE_M4_SPLIT_MAX_B overrides (A/B runs; 0: always one launch)
   static const int v = getenv("KVAE_M4_SPLIT_MAX_B") ? atoi(getenv("KVAE_M4_SPLIT_MAX_B")) : KV_M4_SPLIT_MAX_B;
-  return v;
+  return kv_m4_split_override() >= 0 ? kv_m4_split_override() : v;
 }
 inline bool kv_m4_split(const kvae_lgssm_problem &P_, int do_filter, int do_rts) {
   return do_filter && do_rts && P_.T >= 2 && P_.B <= kv_m4_split_max_b();

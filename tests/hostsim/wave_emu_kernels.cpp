@@ -27,6 +27,11 @@ static void bwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *saved, 
 }
 extern "C" {
 
+int kvae_wemu_m4_split_max_b(int v) {   // < 0: back to the default; returns the previous override
+  const int was = m4::kv_m4_split_override();
+  m4::kv_m4_split_override() = v;
+  return was;
+}
 int kvae_wemu_launches(int which) { return which >= 0 && which < 4 ? g_launches[which] : -1; }
 
 void kvae_wemu_fwd_n4(const kvae_lgssm_problem *p, const kvae_lgssm_states *st, int do_filter, int do_rts) {

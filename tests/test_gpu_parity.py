@@ -439,3 +439,36 @@ def test_ab_switches_select_working_kernels(env):
             % (root, os.path.join(root, "kalman-vae_amd"), os.path.join(root, "tests")))
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_m4_split_and_single_launch_forms_give_the_same_bits():
+    """(4,4,2) below 2048 sequences: chain sweeps + per-step items (3 / 4 launches) against the single-launch form
+    (KVAE_M4_SPLIT_MAX_B=0) on the same inputs, a fresh process each (the switch is read once): all six stacks and every gradient
+    bit for bit - per-step Q, a mask, upstream gradients on all stacks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path[:0] = [%r, %r, %r]; import torch, parity_cases as p\n"
+            "from kvae.kalman.lgssm_ops import LgssmSmooth, Slots, mix_dynamics\n"
+            "B, T, n, K = 37, 23, 4, 3\n"
+            "A, Bm, Cm, alpha, Y, U, mask, _ = p._random_problem(B, T, n, n, 2, K, 4242, 'cuda')\n"
+            "g = torch.Generator().manual_seed(9)\n"
+            "qq = 0.05 * torch.randn(K, n, n, generator=g)\n"
+            "Qk = (0.02 * torch.eye(n).repeat(K, 1, 1) + qq @ qq.mT).cuda()\n"
+            "R, mu0, S0 = 0.03 * torch.eye(2).cuda(), (0.1 * torch.randn(n, generator=g)).cuda(), 2.0 * torch.eye(n).cuda()\n"
+            "w = [(torch.randn(B, T, n, generator=g) if i %% 2 == 0 else torch.randn(B, T, n, n, generator=g)).cuda() for i in range(6)]\n"
+            "leaves = [t.clone().requires_grad_(True) for t in (A, Bm, Qk, alpha, Y, U)]\n"
+            "rec, offs, _ = mix_dynamics(leaves[3], leaves[:3])\n"
+            "outs = LgssmSmooth.apply(leaves[4], leaves[5], mask, rec, None, None, Cm[0], None, R, mu0, S0, "
+            "Slots(A=offs[0], B=offs[1], Q=offs[2]), True)\n"
+            "sum((o * wi).sum() for o, wi in zip(outs, w)).backward()\n"
+            "h = hashlib.sha256()\n"
+            "[h.update(t.detach().cpu().numpy().tobytes()) for t in list(outs) + [l.grad for l in leaves]]\n"
+            "print('DIGEST', h.hexdigest())\n" % (root, os.path.join(root, "kalman-vae_amd"), os.path.join(root, "tests")))
+    digests = []
+    for env in ({}, {"KVAE_M4_SPLIT_MAX_B": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]

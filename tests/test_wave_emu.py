@@ -93,3 +93,33 @@ def test_wave_n16_pivoted_solve(wave_emu_backend):
     parity_cases.n16_indefinite_q("cpu", B=2, T=6)
     after = launches(wave_emu_backend)
     assert after[2] > before[2] and after[3] > before[3]
+
+
+def test_wave_n4_split_and_single_launch_forms_give_the_same_bits(wave_emu_backend):
+    """Below 2048 sequences the (4,4,2) smoother and its adjoint run as "dependent chain, then everything that hangs off it for
+    all steps at once" (3 / 4 launches); above, as one launch each.  Same operations on the same operands: the six stacks and
+    every gradient must agree bit for bit (per-step Q, upstream gradients on all stacks, a mask)."""
+    from kvae.kalman.lgssm_ops import LgssmSmooth, Slots, mix_dynamics
+    B, T, n, m, p, K = 21, 7, 4, 4, 2, 3
+    A, Bm, Cm, alpha, Y, U, mask, _ = parity_cases._random_problem(B, T, n, m, p, K, 4242, "cpu")
+    g = torch.Generator().manual_seed(9)
+    qq = 0.05 * torch.randn(K, n, n, generator=g)
+    Qk = 0.02 * torch.eye(n).repeat(K, 1, 1) + qq @ qq.mT
+    R, mu0, S0 = 0.03 * torch.eye(p), 0.1 * torch.randn(n, generator=g), 2.0 * torch.eye(n)
+    w = [torch.randn(B, T, n, generator=g) if i % 2 == 0 else torch.randn(B, T, n, n, generator=g) for i in range(6)]
+
+    def run(split_max_b):
+        wave_emu_backend.dll.kvae_wemu_m4_split_max_b(split_max_b)
+        leaves = [t.clone().requires_grad_(True) for t in (A, Bm, Qk, alpha, Y, U)]
+        rec, offs, _ = mix_dynamics(leaves[3], leaves[:3])
+        outs = LgssmSmooth.apply(leaves[4], leaves[5], mask, rec, None, None, Cm[0], None, R, mu0, S0,
+                                 Slots(A=offs[0], B=offs[1], Q=offs[2]), True)
+        sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+        return [o.detach() for o in outs] + [t.grad for t in leaves]
+
+    try:
+        split, single = run(1 << 20), run(0)
+    finally:
+        wave_emu_backend.dll.kvae_wemu_m4_split_max_b(-1)
+    for a, b in zip(split, single):
+        assert torch.equal(a, b)
