@@ -34,6 +34,9 @@ lib = _native.lib_for(torch.zeros(1))
 lib.dll.kvae_hostsim_wave_emu(1)
 for dims in ((19, 3, 4, 4, 2, 3), (1, 1, 4, 4, 2, 2), (2, 3, 16, 16, 2, 2)):
     parity_cases.vs_oracle_random("cpu", *dims)
+lib.dll.kvae_wemu_m4_split_max_b(0)      # (4,4,2) again in its single-launch form (the one batches above 2048 sequences take)
+parity_cases.vs_oracle_random("cpu", 19, 4, 4, 4, 2, 3)
+lib.dll.kvae_wemu_m4_split_max_b(-1)
 assert min(lib.dll.kvae_wemu_launches(i) for i in range(4)) > 0
 lib.dll.kvae_hostsim_wave_emu(0)
 print("ASAN-OK")
