@@ -423,12 +423,14 @@ class Trainer:
         regime chain, no library GEMM) the frame pass of configs[1] hides it again and every CU taken from the decoder costs
         (12800 frames: 2.847 / 2.860 / 2.884 / 2.886 ms at 256 / 248 / 240 / 224 workgroups), while below that the chain is
         still the critical path (6400 frames: 1.760 at 224 against 1.799; 3200: 1.212 against 1.250; configs[3]: neutral).
-        The lstm model's chain is hidden at every size."""
+        The lstm model's chain is hidden from 6400 frames on (1.561 / 1.562 / 1.593 ms at 256 / 240 / 224 workgroups there,
+        2.110 / 2.161 / 2.208 at 9600); at 3200 frames it is not (configs[3] with the LSTM alpha-net, T = 100: 1.144 -> 1.118 ms at
+        224; T = 50: 1.040 -> 1.028)."""
         dyn = self.model.kalman_filter.dyn_params
-        if (self.lgssm_stream is not None and getattr(dyn, "is_switching_dynamics", False) and frames < 12800
-                and not self._kf_value_only()):
-            return 224
-        return 256
+        if self.lgssm_stream is None or self._kf_value_only():
+            return 256
+        limit = 12800 if getattr(dyn, "is_switching_dynamics", False) else 4800
+        return 224 if frames < limit else 256
 
     def _capture(self, x, mask=None):
         from .. import _native
