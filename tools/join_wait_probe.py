@@ -10,6 +10,9 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--replays", type=int, default=50)
 ap.add_argument("--dynamics", default="lstm")
+ap.add_argument("--modes", type=int, default=3)
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--seq-len", type=int, default=50)
 args = ap.parse_args()
 import bench
 from kvae.model import model as M
@@ -17,9 +20,9 @@ from kvae.train.synthetic import bouncing_ball
 from kvae.train.train import Trainer
 
 dev = torch.device("cuda:0")
-bargs = argparse.Namespace(dynamics=args.dynamics, modes=3, z_dim=4, seq_len=50)
+bargs = argparse.Namespace(dynamics=args.dynamics, modes=args.modes, z_dim=4, seq_len=args.seq_len)
 cfg, model = bench.build_model(bargs, dev)
-x = bouncing_ball(256, 50, 1234).float().to(dev)
+x = bouncing_ball(args.batch, args.seq_len, 1234).float().to(dev)
 events = {}
 
 
